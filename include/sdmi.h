@@ -1,0 +1,164 @@
+/* sdmi.h - C ABI of libsdmi_hip.so: the MI355X (gfx950) kernels behind the
+ * latent-diffusion denoising hot path (UNet forward + VAE decoder + DDIM update).
+ *
+ * The reference (Charles-yueyue831/StableDiffusion) is pure PyTorch and has no native
+ * plugin/FFI boundary of its own; each entry point below therefore cites
+ * the reference *call sites* whose ATen ops it replaces.  Paths are relative to the reference
+ * repository root.
+ *
+ * Conventions (every entry point):
+ *   - extern "C", plain pointers and sizes; no torch types.
+ *   - all pointers are DEVICE pointers unless the name says host.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no implicit sync.
+ *   - the caller owns and allocates inputs, outputs and workspaces; nothing is allocated or
+ *     freed inside (safe under HIP graph capture).
+ *   - returns SDMI_OK (0) or a negative sdmi_status; never throws.
+ *   - activations are bf16, channels-last: images [B, H, W, C] == token matrices [B*H*W, C].
+ *   - statistics, logits, accumulators and softmax are fp32.
+ */
+#ifndef SDMI_H
+#define SDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sdmi_status {
+    SDMI_OK = 0,
+    SDMI_ERR_BAD_ARG = -1,      /* null pointer / non-positive size / unsupported combination */
+    SDMI_ERR_ALIGNMENT = -2,    /* a leading dimension or channel count breaks the 16-byte vector rule */
+    SDMI_ERR_WORKSPACE = -3,    /* workspace missing or too small */
+    SDMI_ERR_LAUNCH = -4        /* hipLaunchKernel reported an error */
+} sdmi_status;
+
+const char* sdmi_status_str(int status);
+int sdmi_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution on bf16 MFMA (fp32 accumulate):
+ *     out[m, n] = epilogue( alpha * sum_k A[m, k] * W[n, k] )
+ * Replaces: nn.Linear at ldm/modules/attention.py:81,117,213,224,291-296 and
+ * ldm/modules/diffusion/openai_model.py:218,618-620; nn.Conv2d (3x3 s1/s2, 1x1) at
+ * openai_model.py:85,139,195,234,244-248,663,927, ldm/modules/diffusion/model.py:122,329,369,
+ * 433,440,444-448,491-494 and ldm/models/autoencoder.py:54; F.interpolate(x2, nearest)+conv at
+ * openai_model.py:106-114 / model.py:137-141 (fused gather); torch.cat([h, skip]) feeding a 1x1
+ * conv at openai_model.py:1010 (two-pointer A).
+ *
+ * W is PRE-PACKED by the caller: bf16 [Npad][K], K contiguous, Npad = N_w rounded up to 128,
+ * rows >= N_w zero.  K must be a multiple of 64 (pad with zero columns).
+ *   mode 0 (linear / 1x1 conv): A is [M, lda] row-major; if A2 != NULL columns [0,k_split) come
+ *       from A and [k_split,K) from A2 (row stride lda2); k_split % 64 == 0.
+ *   mode 1 (3x3 conv, pad 1): A is an NHWC image [nb, H, W, Cin]; row m = (b, oy, ox) of the
+ *       [nb, Ho, Wo] output; k = (ky*3+kx)*Cin + ci (weights packed in that order); stride 1|2;
+ *       upsample=1 reads the input through a nearest x2 gather (logical input 2H x 2W).
+ *       Cin % 8 == 0; taps beyond 9 (K padding) read as zero.
+ * Epilogue, in this order: *alpha, +bias (per column n, or per row m if bias_per_row),
+ *   GEGLU (geglu=1: W rows hold [16 value | 16 gate] column blocks alternately, bias packed the
+ *   same way; out = value * gelu_erf(gate); N counts gated output columns), act (1 = SiLU),
+ *   +emb[m / rows_per_batch, n] (fp32), +res[m, n] (bf16), store as out_kind.
+ *   out_kind 0: bf16 [M, ld_out]; 1: fp32 [M, ld_out]; 2: fp32 NCHW [M/rows_per_batch, N, rows_per_batch].
+ * batch > 1 runs `batch` independent problems (grid.z) with the element strides given.
+ * split_k > 1 splits K over grid.z (batch must be 1): needs `workspace` of
+ *   sdmi_gemm_workspace_bytes() bytes; partial sums are reduced in a second kernel.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sdmi_gemm_args {
+    const void* A;
+    const void* A2;
+    const void* W;
+    const float* bias;
+    const float* emb;
+    const void* res;
+    void* out;
+    void* workspace;
+    int64_t workspace_bytes;
+    int64_t M, N, K;
+    int64_t lda, lda2, k_split;
+    int64_t ld_res, ld_out, ld_emb, rows_per_batch;
+    int64_t stride_a, stride_w, stride_out, stride_res;   /* elements, for batch > 1 */
+    int32_t mode;
+    int32_t H, W_in, Cin, Ho, Wo, stride, upsample;
+    int32_t out_kind, geglu, act, bias_per_row;
+    int32_t batch, split_k;
+    float alpha;
+} sdmi_gemm_args;
+
+int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
+int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) [+ SiLU] over an NHWC bf16 tensor, fp32 statistics.
+ * Replaces: GroupNorm32 + nn.SiLU at ldm/utils.py:267-278 with openai_model.py:186-190,
+ * 225-235,922-927; nn.GroupNorm(eps 1e-6) at attention.py:45,241; group_norm + swish at
+ * model.py:24-40,404-405,458-466,508.
+ * Input is the channel concatenation [x1 (C1 ch) | x2 (C2 ch)] (x2 may be NULL, C2 = 0): this is
+ * the torch.cat([h, hs.pop()], 1) of openai_model.py:1010 read through two pointers.  Output is
+ * one [nb, hw, C1+C2] tensor.  C1, C2 multiples of 8; (C1+C2) % 32 == 0.
+ * workspace: sdmi_groupnorm_workspace_bytes(nb, hw) bytes of fp32 scratch.
+ * ---------------------------------------------------------------------------------------- */
+int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2,
+                   const float* gamma, const float* beta, void* out,
+                   int32_t nb, int64_t hw, float eps, int32_t silu,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw);
+
+/* LayerNorm over the last dim C of a bf16 [rows, C] matrix, fp32 statistics, affine.
+ * Replaces nn.LayerNorm at attention.py:512-514 (called :525-527).  C % 8 == 0. */
+int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out,
+                   int64_t rows, int32_t C, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flash-style multi-head attention, head dim 64, bf16 in/out, fp32 logits + online softmax.
+ *   out[b, i, h*64 + :] = softmax_j( scale * q[b,i,h,:] . k[b,j,h,:] ) @ v[b,j,h,:]
+ * Replaces CrossAttention.forward at attention.py:315-378 (the einsum/softmax/einsum chain and
+ * the head split/merge rearranges); never materialises the [B*H, Nq, Nk] score tensor.
+ * q rows are [nb*Nq, ldq] with head h at columns [h*64, h*64+64); likewise k, v ([nb*Nk, ld*]) and
+ * out.  All leading dimensions multiples of 8.  Nq, Nk arbitrary (>0).
+ * ---------------------------------------------------------------------------------------- */
+int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out,
+                       int32_t nb, int32_t heads, int32_t Nq, int32_t Nk,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                       float scale, void* stream);
+
+/* Row / column softmax helpers for the VAE single-head attention (model.py:514-523), whose
+ * score matrix S is produced by sdmi_gemm (out_kind 1).
+ *   rows: P[i, j] = softmax_j S[i, j]            (bf16 out)       - "standard" mode
+ *   cols: PT[j, i] = softmax_j ST[j, i] for each column i of ST    - "reference" mode, where
+ *         ST[j, i] = scale * k_j . q_i, so PT = W^T with W row-normalised over j (model.py:521-523).
+ * colstats: fp32 scratch of sdmi_softmax_cols_scratch_bytes(batch, cols) bytes. */
+int sdmi_softmax_rows(const float* S, void* P, int64_t rows, int64_t cols, int64_t ld_s, int64_t ld_p,
+                      void* stream);
+int sdmi_softmax_cols(const float* ST, void* PT, float* colstats, int32_t batch, int64_t rows, int64_t cols,
+                      void* stream);
+int64_t sdmi_softmax_cols_scratch_bytes(int32_t batch, int64_t cols);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / elementwise kernels at the edges of the path.
+ * ---------------------------------------------------------------------------------------- */
+/* fp32 NCHW [nb, C, hw] -> bf16 NHWC [nb, hw, Cpad] (channels >= C zero), value * scale.
+ * Entry of UNetModel.forward (openai_model.py:980) and of decode_first_stage (z / scale_factor,
+ * configs/stable-diffusion/v2-inference.yaml:17). */
+int sdmi_nchw_f32_to_nhwc_bf16(const float* x, void* out, int32_t nb, int32_t C, int32_t Cpad, int64_t hw,
+                               float scale, void* stream);
+/* fp32 -> bf16 cast of a contiguous buffer (context embeddings, openai_model.py:940 `context`). */
+int sdmi_f32_to_bf16(const float* x, void* out, int64_t n, void* stream);
+/* Sinusoidal timestep embedding, cos first then sin (ldm/utils.py:301-318, repaired B1/B2):
+ * out bf16 [nb, dim]. t is int64 [nb]. dim even. */
+int sdmi_timestep_embedding(const int64_t* t, void* out, int32_t nb, int32_t dim, float max_period, void* stream);
+/* Classifier-free-guidance combine + DDIM update on fp32 NCHW latents (the loop body absent from
+ * ldm/models/diffusion/ddim.py:184-249; semantics SURVEY.md §3.2).  model_out holds the UNet output
+ * for [uncond batch | cond batch] (2*n elements) when e_uc_first != 0, else n elements.
+ * v_param selects v-prediction.  noise may be NULL (sigma == 0). Writes x_prev and pred_x0 (may be NULL). */
+int sdmi_ddim_step(const float* x, const float* model_out, const float* noise, float* x_prev, float* pred_x0,
+                   int64_t n, int32_t cfg, float guidance_scale, float a_t, float a_prev, float sigma_t,
+                   float sqrt_one_minus_a_t, int32_t v_param, void* stream);
+/* clamp((x + 1) / 2, 0, 1) * 255 -> uint8, NCHW fp32 in, NHWC uint8 out (the image post-processing that
+ * follows decode_first_stage in upstream txt2img; absent after scripts/txt2img.py:402). */
+int sdmi_image_to_u8(const float* x, uint8_t* out, int32_t nb, int32_t C, int64_t hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H */

@@ -1,0 +1,47 @@
+// Shared device helpers for the sdmi gfx950 kernels (bf16 packing, MFMA vector types).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sdmi.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SDMI_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return SDMI_ERR_LAUNCH; \
+    } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+
+// Round-to-nearest-even f32 -> bf16 through the hardware convert (keeps NaN a NaN).
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

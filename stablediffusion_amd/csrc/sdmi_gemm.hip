@@ -1,0 +1,450 @@
+// sdmi_gemm: bf16 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   out[m, n] = epilogue(alpha * sum_k A[m, k] * W[n, k])          (see include/sdmi.h)
+//
+// One kernel serves nn.Linear, conv1x1 and conv3x3 (stride 1/2, optional fused nearest-x2
+// gather, optional two-pointer channel concat): they differ only in how a 128-row x 64-k tile
+// of A is gathered from HBM.  Both operands are K-contiguous, so both MFMA fragments are plain
+// 16-byte LDS reads.
+//
+// Tiling: 128(M) x 128(N) x 64(K) per 256-thread workgroup; 4 waves as 2x2, each wave a 64x64
+// sub-tile = 4x4 MFMA 16x16x32 tiles (64 fp32 accumulators).  The MFMA "A" operand is the W
+// tile and the "B" operand is the activation tile, so an accumulator register quad holds 4
+// CONSECUTIVE output columns of one output row: epilogue loads/stores are 8-16 byte vectors.
+// LDS: double-buffered A and W tiles, 64 KiB, XOR-swizzled 16-byte chunks (conflict-free
+// ds_read_b128); global loads for tile k+1 are issued before the MFMAs of tile k and written
+// to LDS after them (register staging: the conv gather needs per-lane addresses and zero fill).
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous, group-M-swizzled
+// range of tiles.
+#include "sdmi_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NTHREADS = 256;
+constexpr int TILE_CHUNKS = BM * (BK / 8);          // 16-byte chunks per operand tile (1024)
+constexpr int LDS_BYTES = 4 * TILE_CHUNKS * 16;     // A0 A1 W0 W1 = 64 KiB
+constexpr int GROUP_M = 8;
+
+struct TileCoord { int tm, tn; };
+
+__device__ __forceinline__ TileCoord tile_of_block(int bid, int tiles_m, int tiles_n) {
+    const int nwg = tiles_m * tiles_n;
+    // XCD-aware bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous range.
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // group-M swizzle inside the range
+    const int per_group = GROUP_M * tiles_n;
+    const int g = lid / per_group;
+    const int first_m = g * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_g = lid - g * per_group;
+    TileCoord t;
+    t.tm = first_m + in_g % gsz;
+    t.tn = in_g / gsz;
+    return t;
+}
+
+// Loads of invalid rows / taps go to an always-valid address and are zeroed BY VALUE (a `c ? *p : zero`
+// expression makes clang select between ADDRESSES, one of them a scratch copy of the zero).
+__device__ __forceinline__ uint4 mask4(uint4 v, unsigned ok) {
+    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    return v;
+}
+
+// Epilogue for 4 consecutive output columns of one row.  `v` is the raw accumulator quad (already
+// scaled and biased by the caller for the column-bias / GEGLU cases).
+__device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, int64_t n, f32x4 v,
+                                           int64_t zoff_out, int64_t zoff_res) {
+    if (p.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+    }
+    if (p.bias != nullptr && p.bias_per_row) {
+        const float b = p.bias[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b;
+    }
+    const bool full = (n + 3 < p.N);
+    if (p.emb != nullptr) {
+        const float* e = p.emb + (m / p.rows_per_batch) * p.ld_emb + n;
+        if (full) {
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(e);
+            v += ev;
+        } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += e[j];
+        }
+    }
+    if (p.res != nullptr) {
+        const unsigned short* r = reinterpret_cast<const unsigned short*>(p.res) + zoff_res + m * p.ld_res + n;
+        if (full) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(r);
+            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += bf16_bits_to_f32(r[j]);
+        }
+    }
+    if (p.out_kind == 0) {
+        unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n;
+        if (full) {
+            uint2 ov;
+            ov.x = pack_bf16x2(v[0], v[1]);
+            ov.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(o) = ov;
+        } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = f32_to_bf16_bits(v[j]);
+        }
+    } else if (p.out_kind == 1) {
+        float* o = reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n;
+        if (full) {
+            *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = v[j];
+        }
+    } else {  // fp32 NCHW
+        const int64_t b = m / p.rows_per_batch, pix = m - b * p.rows_per_batch;
+        float* o = reinterpret_cast<float*>(p.out) + zoff_out + (b * p.N + n) * p.rows_per_batch + pix;
+        for (int j = 0; j < 4 && n + j < p.N; ++j) o[j * p.rows_per_batch] = v[j];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* const As = reinterpret_cast<uint4*>(smem);
+    uint4* const Ws = reinterpret_cast<uint4*>(smem) + 2 * TILE_CHUNKS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    const int64_t n_w = p.geglu ? 2 * p.N : p.N;          // weight rows in use
+    const int tiles_m = (int)((p.M + BM - 1) / BM);
+    const int tiles_n = (int)((n_w + BN - 1) / BN);
+    const TileCoord tc = tile_of_block(blockIdx.x, tiles_m, tiles_n);
+    const int64_t m0 = (int64_t)tc.tm * BM;
+    const int64_t n0 = (int64_t)tc.tn * BN;
+
+    // grid.z is either the batch index or the split-K slice
+    const int z = blockIdx.z;
+    const int nk_total = (int)(p.K / BK);
+    int kt_begin = 0, kt_end = nk_total;
+    int64_t zoff_a = 0, zoff_w = 0, zoff_out = 0, zoff_res = 0;
+    if (p.split_k > 1) {
+        const int per = (nk_total + p.split_k - 1) / p.split_k;
+        kt_begin = z * per;
+        kt_end = min(nk_total, kt_begin + per);
+    } else {
+        zoff_a = z * p.stride_a; zoff_w = z * p.stride_w; zoff_out = z * p.stride_out; zoff_res = z * p.stride_res;
+    }
+
+    const unsigned short* const A = reinterpret_cast<const unsigned short*>(p.A) + zoff_a;
+    const unsigned short* const A2 = reinterpret_cast<const unsigned short*>(p.A2);
+    const unsigned short* const W = reinterpret_cast<const unsigned short*>(p.W) + zoff_w;
+
+    // ---- loader geometry: thread owns 16-byte chunk `lc` of rows lr + 32*i ----
+    const int lc = tid & 7;
+    const int lr = tid >> 3;
+
+    int64_t a_off[4];      // MODE 0: m * lda (and m*lda2 recomputed);  MODE 1: pixel base b*H*W
+    int iy0[4], ix0[4];    // MODE 1
+    bool rvalid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + lr + 32 * i;
+        rvalid[i] = m < p.M;
+        if (MODE == 0) {
+            a_off[i] = m;
+        } else {
+            const int64_t hw = (int64_t)p.Ho * p.Wo;
+            const int64_t b = m / hw;
+            const int rem = (int)(m - b * hw);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_off[i] = b * (int64_t)p.H * p.W_in;
+            iy0[i] = rvalid[i] ? oy * p.stride - 1 : -(1 << 20);
+            ix0[i] = ox * p.stride - 1;
+        }
+    }
+    const unsigned rowmask = (rvalid[0] ? 1u : 0u) | (rvalid[1] ? 2u : 0u) | (rvalid[2] ? 4u : 0u) | (rvalid[3] ? 8u : 0u);
+    const int Hl = p.H << p.upsample, Wl = p.W_in << p.upsample;
+    // conv k-state for this thread's chunk: k = kt*64 + lc*8 -> (tap, ci)
+    int c_tap = 0, c_ci = 0;
+    if (MODE == 1) {
+        const int k = kt_begin * BK + lc * 8;
+        c_tap = k / p.Cin;
+        c_ci = k - c_tap * p.Cin;
+    }
+
+    const unsigned short* w_ptr = W + (n0 + lr) * p.K + (int64_t)kt_begin * BK + lc * 8;
+    const int64_t w_row32 = 32 * p.K;
+
+    // Register staging for the next k-tile.  Named scalars, not arrays: hipcc keeps a uint4[4] that is
+    // written in one branch and read in another in scratch memory.
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+
+    // The zero fill of invalid rows/taps is applied when the registers are written to LDS (okmask), so the
+    // global loads stay in flight across the MFMAs of the current tile.
+    unsigned okmask = 0;
+#define SDMI_LOAD_A0(I, DST, KK, BASE, LD) \
+    DST = *reinterpret_cast<const uint4*>((BASE) + (rvalid[I] ? a_off[I] * (LD) + (KK) : 0))
+#define SDMI_LOAD_A1(I, DST, KY, KX, TV)                                                               \
+    do {                                                                                               \
+        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                  \
+        const bool ok_ = (TV) && (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;         \
+        iy_ >>= p.upsample; ix_ >>= p.upsample;                                                        \
+        const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin + c_ci;                  \
+        okmask |= (ok_ ? 1u : 0u) << (I);                                                              \
+        DST = *reinterpret_cast<const uint4*>(A + (ok_ ? off_ : 0));                                   \
+    } while (0)
+
+#define SDMI_LOAD_TILE(KT)                                                                             \
+    do {                                                                                               \
+        if (MODE == 0) {                                                                               \
+            const int64_t k_ = (int64_t)(KT) * BK + lc * 8;                                            \
+            const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                 \
+            const unsigned short* base_ = second_ ? A2 : A;                                            \
+            const int64_t ld_ = second_ ? p.lda2 : p.lda;                                              \
+            const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                         \
+            SDMI_LOAD_A0(0, ra0, kk_, base_, ld_); SDMI_LOAD_A0(1, ra1, kk_, base_, ld_);              \
+            SDMI_LOAD_A0(2, ra2, kk_, base_, ld_); SDMI_LOAD_A0(3, ra3, kk_, base_, ld_);              \
+            okmask = rowmask;                                                                          \
+        } else {                                                                                       \
+            const int ky_ = c_tap / 3, kx_ = c_tap - 3 * ky_;                                          \
+            const bool tapvalid_ = c_tap < 9;                                                          \
+            okmask = 0;                                                                                \
+            SDMI_LOAD_A1(0, ra0, ky_, kx_, tapvalid_); SDMI_LOAD_A1(1, ra1, ky_, kx_, tapvalid_);      \
+            SDMI_LOAD_A1(2, ra2, ky_, kx_, tapvalid_); SDMI_LOAD_A1(3, ra3, ky_, kx_, tapvalid_);      \
+            c_ci += BK;                                                                                \
+            while (c_ci >= p.Cin) { c_ci -= p.Cin; ++c_tap; }                                          \
+        }                                                                                              \
+        rw0 = *reinterpret_cast<const uint4*>(w_ptr);                                                  \
+        rw1 = *reinterpret_cast<const uint4*>(w_ptr + w_row32);                                        \
+        rw2 = *reinterpret_cast<const uint4*>(w_ptr + 2 * w_row32);                                    \
+        rw3 = *reinterpret_cast<const uint4*>(w_ptr + 3 * w_row32);                                    \
+        w_ptr += BK;                                                                                   \
+    } while (0)
+
+    // LDS chunk index of row lr + 32*i: (lr + 32 i) * 8 + (lc ^ (lr & 7))
+    const int st_idx = lr * 8 + (lc ^ (lr & 7));
+#define SDMI_STORE_TILE(BUF)                                                                           \
+    do {                                                                                               \
+        uint4* a_ = As + (BUF) * TILE_CHUNKS + st_idx;                                                 \
+        uint4* w_ = Ws + (BUF) * TILE_CHUNKS + st_idx;                                                 \
+        a_[0] = mask4(ra0, okmask & 1u); a_[256] = mask4(ra1, okmask & 2u);                            \
+        a_[512] = mask4(ra2, okmask & 4u); a_[768] = mask4(ra3, okmask & 8u);                          \
+        w_[0] = rw0; w_[256] = rw1; w_[512] = rw2; w_[768] = rw3;                                      \
+    } while (0)
+
+    f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    const int a_base = (wm * 64 + frow) * 8;
+    const int w_base = (wn * 64 + frow) * 8;
+
+    if (kt_begin < kt_end) {
+        SDMI_LOAD_TILE(kt_begin);
+        SDMI_STORE_TILE(0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
+        if (more) SDMI_LOAD_TILE(kt + 1);
+        const uint4* Ab = As + cur * TILE_CHUNKS;
+        const uint4* Wb = Ws + cur * TILE_CHUNKS;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pc = (ks * 4 + fq) ^ (frow & 7);
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = __builtin_bit_cast(bf16x8, Ab[a_base + i * 128 + pc]);
+                wf[i] = __builtin_bit_cast(bf16x8, Wb[w_base + i * 128 + pc]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (more) SDMI_STORE_TILE(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*64 + mi*16 + (lane&15),
+    // weight row (column of out) wcol = n0 + wn*64 + ni*16 + 4*(lane>>4) + j.
+    if (p.split_k > 1) {
+        // raw partial sums to the workspace slab of this slice: [split][M][tiles_n*BN] fp32
+        float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)z * p.M * ((int64_t)tiles_n * BN);
+        const int64_t ldw = (int64_t)tiles_n * BN;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int64_t m = m0 + wm * 64 + mi * 16 + frow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int64_t wcol = n0 + wn * 64 + ni * 16 + 4 * fq;
+                *reinterpret_cast<f32x4*>(ws + m * ldw + wcol) = acc[ni][mi];
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 16 + frow;
+        if (m >= p.M) continue;
+        if (p.geglu) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int64_t wcol = n0 + wn * 64 + ni * 16 + 4 * fq;
+                const int64_t n = (wcol >> 5) * 16 + (wcol & 15);
+                if (n >= p.N) continue;
+                f32x4 v = acc[ni][mi] * p.alpha, g = acc[ni + 1][mi] * p.alpha;
+                if (p.bias != nullptr) {
+                    v += *reinterpret_cast<const f32x4*>(p.bias + wcol);
+                    g += *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+                store_quad(p, m, n, v, zoff_out, zoff_res);
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int64_t n = n0 + wn * 64 + ni * 16 + 4 * fq;
+                if (n >= p.N) continue;
+                f32x4 v = acc[ni][mi] * p.alpha;
+                if (p.bias != nullptr && !p.bias_per_row) {
+                    if (n + 3 < p.N) {
+                        v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    } else {
+                        for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
+                    }
+                }
+                store_quad(p, m, n, v, zoff_out, zoff_res);
+            }
+        }
+    }
+}
+
+// Second pass of split-K: sum the slabs and run the same epilogue.  One thread per output quad.
+__global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_args p, int64_t ldw) {
+    const int64_t n_w = p.geglu ? 2 * p.N : p.N;
+    const int64_t quads_per_row = (n_w + 3) / 4;
+    const int64_t total = p.M * quads_per_row;
+    const float* ws = reinterpret_cast<const float*>(p.workspace);
+    const int64_t slab = p.M * ldw;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / quads_per_row;
+        const int64_t wcol = (idx - m * quads_per_row) * 4;
+        if (p.geglu && (wcol & 16)) continue;   // gate quads are consumed with their value quad
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f}, g = v;
+        for (int s = 0; s < p.split_k; ++s) {
+            v += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol);
+            if (p.geglu) g += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol + 16);
+        }
+        v *= p.alpha;
+        int64_t n = wcol;
+        if (p.geglu) {
+            g *= p.alpha;
+            n = (wcol >> 5) * 16 + (wcol & 15);
+            if (p.bias != nullptr) {
+                v += *reinterpret_cast<const f32x4*>(p.bias + wcol);
+                g += *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+        } else if (p.bias != nullptr && !p.bias_per_row) {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
+        }
+        if (n >= p.N) continue;
+        store_quad(p, m, n, v, 0, 0);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k) {
+    if (split_k <= 1) return 0;
+    const int64_t ldw = (N_w + BN - 1) / BN * BN;
+    return (int64_t)split_k * M * ldw * (int64_t)sizeof(float);
+}
+
+extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
+    if (a == nullptr || a->A == nullptr || a->W == nullptr || a->out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return SDMI_ERR_BAD_ARG;
+    if (a->K % BK != 0) return SDMI_ERR_ALIGNMENT;
+    if (a->mode != 0 && a->mode != 1) return SDMI_ERR_BAD_ARG;
+    if (a->out_kind < 0 || a->out_kind > 2) return SDMI_ERR_BAD_ARG;
+    const int batch = a->batch > 0 ? a->batch : 1;
+    const int split = a->split_k > 0 ? a->split_k : 1;
+    if (batch > 1 && split > 1) return SDMI_ERR_BAD_ARG;
+    if (a->geglu && (a->N % 16 != 0)) return SDMI_ERR_ALIGNMENT;
+    if ((a->emb != nullptr || a->out_kind == 2) && a->rows_per_batch <= 0) return SDMI_ERR_BAD_ARG;
+    if (a->emb != nullptr && (a->ld_emb % 4 != 0)) return SDMI_ERR_ALIGNMENT;
+    if (a->res != nullptr && (a->ld_res % 4 != 0)) return SDMI_ERR_ALIGNMENT;
+    if (a->out_kind != 2 && (a->ld_out % 4 != 0)) return SDMI_ERR_ALIGNMENT;
+    if (a->mode == 0) {
+        if (a->lda % 8 != 0) return SDMI_ERR_ALIGNMENT;
+        if (a->A2 != nullptr) {
+            if (a->lda2 % 8 != 0 || a->k_split % BK != 0 || a->k_split <= 0 || a->k_split >= a->K)
+                return SDMI_ERR_ALIGNMENT;
+        }
+    } else {
+        if (a->Cin <= 0 || a->Cin % 8 != 0) return SDMI_ERR_ALIGNMENT;
+        if (a->H <= 0 || a->W_in <= 0 || a->Ho <= 0 || a->Wo <= 0) return SDMI_ERR_BAD_ARG;
+        if (a->stride != 1 && a->stride != 2) return SDMI_ERR_BAD_ARG;
+        if (a->upsample != 0 && a->upsample != 1) return SDMI_ERR_BAD_ARG;
+        if (a->M % ((int64_t)a->Ho * a->Wo) != 0) return SDMI_ERR_BAD_ARG;
+        if (a->K < 9 * (int64_t)a->Cin) return SDMI_ERR_BAD_ARG;
+        // output geometry must match the (possibly upsampled) input
+        const int Hl = a->H << a->upsample, Wl = a->W_in << a->upsample;
+        if ((Hl + 2 - 3) / a->stride + 1 != a->Ho || (Wl + 2 - 3) / a->stride + 1 != a->Wo) return SDMI_ERR_BAD_ARG;
+        if (a->A2 != nullptr) return SDMI_ERR_BAD_ARG;
+    }
+    sdmi_gemm_args p = *a;
+    p.batch = batch;
+    p.split_k = split;
+    const int64_t n_w = p.geglu ? 2 * p.N : p.N;
+    const int64_t tiles_m = (p.M + BM - 1) / BM, tiles_n = (n_w + BN - 1) / BN;
+    if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
+    if (split > 1) {
+        if (split > p.K / BK) return SDMI_ERR_BAD_ARG;
+        if (p.workspace == nullptr || p.workspace_bytes < sdmi_gemm_workspace_bytes(p.M, n_w, split))
+            return SDMI_ERR_WORKSPACE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
+    if (p.mode == 0)
+        hipLaunchKernelGGL(sdmi_gemm_kernel<0>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
+    else
+        hipLaunchKernelGGL(sdmi_gemm_kernel<1>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
+    SDMI_CHECK_LAUNCH();
+    if (split > 1) {
+        const int64_t quads = p.M * ((n_w + 3) / 4);
+        const int64_t blocks = (quads + 255) / 256;
+        hipLaunchKernelGGL(sdmi_gemm_splitk_reduce, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, p,
+                           tiles_n * BN);
+        SDMI_CHECK_LAUNCH();
+    }
+    return SDMI_OK;
+}

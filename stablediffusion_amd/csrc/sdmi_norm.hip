@@ -1,0 +1,253 @@
+// sdmi_norm: GroupNorm(32)+SiLU and LayerNorm for NHWC bf16 activations on gfx950.
+//
+// Both are HBM-bound: every global access is a 16-byte (8 x bf16) vector, fully coalesced because an
+// NHWC tensor [nb, hw, C] is one contiguous [nb*hw, C] matrix.  Statistics are fp32.
+//
+// GroupNorm runs as three launches on the caller's stream:
+//   1. gn_stats:    grid (slabs, nb) - each block reduces a slab of pixels to per-group (n, mean, M2)
+//   2. gn_finalize: grid (nb)        - Chan/Welford merge of the slab partials -> (mean, rstd) per group
+//   3. gn_apply:    grid (slabs, nb) - y = silu(x * scale[c] + shift[c]) with scale/shift tables in LDS
+// The second read of x in pass 3 is served from L2 / Infinity Cache for the UNet's tensor sizes.
+// The input may be the channel concatenation of two tensors (two base pointers).
+#include "sdmi_common.h"
+
+namespace {
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_THREADS = 256;
+
+__host__ __device__ inline int64_t gn_slab_pixels(int64_t hw) {
+    // at most 256 slabs per image, at least 64 pixels per slab
+    int64_t p = (hw + 255) / 256;
+    if (p < 64) p = 64;
+    return p;
+}
+
+__device__ __forceinline__ uint4 gn_load(const unsigned short* x1, const unsigned short* x2, int C1, int C2,
+                                         int64_t pixel, int v) {
+    const int c = v * 8;
+    if (c < C1) return *reinterpret_cast<const uint4*>(x1 + pixel * C1 + c);
+    return *reinterpret_cast<const uint4*>(x2 + pixel * C2 + (c - C1));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned short* __restrict__ x1,
+                                                              const unsigned short* __restrict__ x2, int C1, int C2,
+                                                              int64_t hw, int64_t P, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [2][C]
+    const int C = C1 + C2, nvec = C >> 3, cpg = C / GN_GROUPS;
+    const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += GN_THREADS) sh[i] = 0.f;
+    __syncthreads();
+
+    const int cols = nvec < GN_THREADS ? nvec : GN_THREADS;
+    const int rows = GN_THREADS / cols;
+    const int tcol = tid % cols, trow = tid / cols;
+    const int64_t p_begin = (int64_t)slab * P;
+    const int64_t p_end = (p_begin + P < hw) ? p_begin + P : hw;
+    if (trow < rows) {
+        for (int v = tcol; v < nvec; v += cols) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+            for (int64_t pix = p_begin + trow; pix < p_end; pix += rows) {
+                const uint4 raw = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix, v);
+                float f[8];
+                unpack_bf16x8(raw, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&sh[v * 8 + j], s[j]);
+                atomicAdd(&sh[C + v * 8 + j], ss[j]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+        float S = 0.f, SS = 0.f;
+        for (int j = 0; j < cpg; ++j) { S += sh[tid * cpg + j]; SS += sh[C + tid * cpg + j]; }
+        const float n = (float)((p_end - p_begin) * cpg);
+        const float mean = S / n;
+        float m2 = SS - S * mean;
+        if (m2 < 0.f) m2 = 0.f;
+        float* o = partial + (((int64_t)b * nslab + slab) * GN_GROUPS + tid) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nslab, float eps,
+                                                         float* __restrict__ stats) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    if (g >= GN_GROUPS) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < nslab; ++s) {
+        const float* pp = partial + (((int64_t)b * nslab + s) * GN_GROUPS + g) * 3;
+        const float nb = pp[0], mb = pp[1], m2b = pp[2];
+        const float tot = n + nb;
+        const float delta = mb - mean;
+        mean += delta * (nb / tot);
+        m2 += m2b + delta * delta * (n * nb / tot);
+        n = tot;
+    }
+    const float var = m2 / n;
+    stats[((int64_t)b * GN_GROUPS + g) * 2 + 0] = mean;
+    stats[((int64_t)b * GN_GROUPS + g) * 2 + 1] = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned short* __restrict__ x1,
+                                                              const unsigned short* __restrict__ x2, int C1, int C2,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ stats,
+                                                              unsigned short* __restrict__ out, int64_t hw, int64_t P,
+                                                              int silu) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // scale[C], shift[C]
+    const int C = C1 + C2, nvec = C >> 3, cpg = C / GN_GROUPS;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += GN_THREADS) {
+        const int g = c / cpg;
+        const float mean = stats[((int64_t)b * GN_GROUPS + g) * 2], rstd = stats[((int64_t)b * GN_GROUPS + g) * 2 + 1];
+        const float sc = rstd * gamma[c];
+        sh[c] = sc;
+        sh[C + c] = beta[c] - mean * sc;
+    }
+    __syncthreads();
+    const int cols = nvec < GN_THREADS ? nvec : GN_THREADS;
+    const int rows = GN_THREADS / cols;
+    const int tcol = tid % cols, trow = tid / cols;
+    if (trow >= rows) return;
+    const int64_t p_begin = (int64_t)slab * P;
+    const int64_t p_end = (p_begin + P < hw) ? p_begin + P : hw;
+    for (int v = tcol; v < nvec; v += cols) {
+        float sc[8], sf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = sh[v * 8 + j]; sf[j] = sh[C + v * 8 + j]; }
+        for (int64_t pix = p_begin + trow; pix < p_end; pix += rows) {
+            const int64_t gp = (int64_t)b * hw + pix;
+            const uint4 raw = gn_load(x1, x2, C1, C2, gp, v);
+            float f[8];
+            unpack_bf16x8(raw, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = f[j] * sc[j] + sf[j];
+                f[j] = silu ? silu_f(y) : y;
+            }
+            *reinterpret_cast<uint4*>(out + gp * C + v * 8) = pack_bf16x8(f);
+        }
+    }
+}
+
+// LayerNorm: one wave per row, row held in registers (C <= 2048), exact two-pass statistics.
+constexpr int LN_MAXV = 4;   // 64 lanes x 4 vectors x 8 = 2048 channels
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        unsigned short* __restrict__ out, int64_t rows, int C,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nvec = C >> 3;
+    const float inv_c = 1.0f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const unsigned short* xr = x + row * C;
+        float f[LN_MAXV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(xr + v * 8);
+                unpack_bf16x8(raw, f[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += f[i][j];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * inv_c + eps);
+        unsigned short* orow = out + row * C;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
+                    y[4 + j] = (f[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+                }
+                *reinterpret_cast<uint4*>(orow + v * 8) = pack_bf16x8(y);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw) {
+    const int64_t P = gn_slab_pixels(hw);
+    const int64_t nslab = (hw + P - 1) / P;
+    return ((int64_t)nb * nslab * GN_GROUPS * 3 + (int64_t)nb * GN_GROUPS * 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma,
+                              const float* beta, void* out, int32_t nb, int64_t hw, float eps, int32_t silu,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    if (x1 == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (nb <= 0 || hw <= 0 || C1 <= 0 || C2 < 0) return SDMI_ERR_BAD_ARG;
+    if ((x2 == nullptr) != (C2 == 0)) return SDMI_ERR_BAD_ARG;
+    const int C = C1 + C2;
+    if (C1 % 8 != 0 || C2 % 8 != 0 || C % GN_GROUPS != 0) return SDMI_ERR_ALIGNMENT;
+    if (2 * C * (int)sizeof(float) > 64 * 1024) return SDMI_ERR_BAD_ARG;
+    if (workspace == nullptr || workspace_bytes < sdmi_groupnorm_workspace_bytes(nb, hw)) return SDMI_ERR_WORKSPACE;
+    const int64_t P = gn_slab_pixels(hw);
+    const int nslab = (int)((hw + P - 1) / P);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* stats = partial + (int64_t)nb * nslab * GN_GROUPS * 3;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)nslab, (unsigned)nb);
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), lds, s, reinterpret_cast<const unsigned short*>(x1),
+                       reinterpret_cast<const unsigned short*>(x2), C1, C2, hw, P, partial);
+    SDMI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(64), 0, s, partial, nslab, eps, stats);
+    SDMI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), lds, s, reinterpret_cast<const unsigned short*>(x1),
+                       reinterpret_cast<const unsigned short*>(x2), C1, C2, gamma, beta, stats,
+                       reinterpret_cast<unsigned short*>(out), hw, P, silu);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows,
+                              int32_t C, float eps, void* stream) {
+    if (x == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (rows <= 0 || C <= 0) return SDMI_ERR_BAD_ARG;
+    if (C % 8 != 0 || C > 64 * LN_MAXV * 8) return SDMI_ERR_ALIGNMENT;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
+                       rows, C, eps);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}

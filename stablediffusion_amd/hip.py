@@ -1,0 +1,84 @@
+"""ctypes binding of libsdmi_hip.so (the C ABI declared in include/sdmi.h).
+
+The library is built in-tree (``stablediffusion_amd/csrc/libsdmi_hip.so``) by
+``__graft_entry__.build()`` / ``make -C stablediffusion_amd/csrc``.  There is no
+fallback: if the library is missing, loading raises and every op fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdmi_hip.so")
+
+SDMI_OK = 0
+
+
+class SdmiError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    """Mirror of ``sdmi_gemm_args`` (include/sdmi.h) - field order and types must match."""
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p),
+        ("bias", C.c_void_p), ("emb", C.c_void_p), ("res", C.c_void_p),
+        ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("lda", C.c_int64), ("lda2", C.c_int64), ("k_split", C.c_int64),
+        ("ld_res", C.c_int64), ("ld_out", C.c_int64), ("ld_emb", C.c_int64), ("rows_per_batch", C.c_int64),
+        ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
+        ("mode", C.c_int32),
+        ("H", C.c_int32), ("W_in", C.c_int32), ("Cin", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32),
+        ("out_kind", C.c_int32), ("geglu", C.c_int32), ("act", C.c_int32), ("bias_per_row", C.c_int32),
+        ("batch", C.c_int32), ("split_k", C.c_int32),
+        ("alpha", C.c_float),
+    ]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/sdmi.h declares
+SIGNATURES = {
+    "sdmi_status_str": (C.c_char_p, [C.c_int]),
+    "sdmi_abi_version": (C.c_int, []),
+    "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "sdmi_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp]),
+    "sdmi_groupnorm_workspace_bytes": (_i64, [_i32, _i64]),
+    "sdmi_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "sdmi_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "sdmi_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "sdmi_softmax_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp]),
+    "sdmi_softmax_cols_scratch_bytes": (_i64, [_i32, _i64]),
+    "sdmi_nchw_f32_to_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _vp]),
+    "sdmi_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sdmi_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
+    "sdmi_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "sdmi_image_to_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises SdmiError when the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdmiError(
+                f"{LIB_PATH} not found: build it with `make -C stablediffusion_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU/PyTorch fallback for the HIP path")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what=""):
+    if status != SDMI_OK:
+        msg = lib().sdmi_status_str(status).decode()
+        raise SdmiError(f"{what or 'sdmi call'} failed: {msg} ({status})")

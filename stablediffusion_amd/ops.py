@@ -1,0 +1,361 @@
+"""Tensor-level wrappers over the C ABI (include/sdmi.h): torch supplies device memory and the
+stream, the arithmetic happens in libsdmi_hip.so.  No op here has a PyTorch fallback.
+
+Activation convention: bf16, channels-last.  An image batch is a contiguous [B, H, W, C] tensor,
+which *is* the token matrix [B*H*W, C] the transformer blocks use (no permutes anywhere).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import hip
+
+BF16 = torch.bfloat16
+_BN = 128   # weight-row padding (GEMM N tile)
+_BK = 64    # K padding (GEMM K tile)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise hip.SdmiError(f"{name}: the HIP path needs device tensors (got {t.device}); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise hip.SdmiError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise hip.SdmiError(f"{name}: tensor must be contiguous")
+
+
+# ----------------------------------------------------------------------------- weight packing
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class PackedWeight:
+    """bf16 [Npad, Kpad] weight (K contiguous) + fp32 bias in the layout sdmi_gemm expects."""
+
+    def __init__(self, w, bias, n_out, k, geglu=False, cin=None):
+        self.w = w              # bf16 [Npad, Kpad]
+        self.bias = bias        # fp32 [n_w] or None
+        self.n_out = n_out      # output columns (after gating)
+        self.k = k              # padded K
+        self.geglu = geglu
+        self.cin = cin          # conv3x3: (padded) input channels
+
+
+def _pad_pack(w2d):
+    n, k = w2d.shape
+    out = torch.zeros(_round_up(n, _BN), _round_up(k, _BK), dtype=BF16, device=w2d.device)
+    out[:n, :k] = w2d.to(BF16)
+    return out
+
+
+def pack_linear(weight, bias=None):
+    """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
+    w = weight.detach().reshape(weight.shape[0], -1).float()
+    b = bias.detach().float().contiguous() if bias is not None else None
+    packed = _pad_pack(w)
+    return PackedWeight(packed, b, w.shape[0], packed.shape[1])
+
+
+def pack_linear_cat(weights, biases=None):
+    """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections)."""
+    w = torch.cat([x.detach().reshape(x.shape[0], -1).float() for x in weights], dim=0)
+    b = None
+    if biases is not None:
+        b = torch.cat([x.detach().float() for x in biases]).contiguous()
+    packed = _pad_pack(w)
+    return PackedWeight(packed, b, w.shape[0], packed.shape[1])
+
+
+def pack_geglu(weight, bias):
+    """GEGLU projection [2*inner, K]: rows [0,inner) = value, [inner,2*inner) = gate (attention.py:89).
+    Packed row r holds value (half 0) or gate (half 1) column blk*16+i with blk=r//32, half=(r%32)//16, i=r%16."""
+    w = weight.detach().float()
+    inner = w.shape[0] // 2
+    assert inner % 16 == 0
+    r = torch.arange(2 * inner, device=w.device)
+    src = ((r % 32) // 16) * inner + (r // 32) * 16 + (r % 16)
+    packed = _pad_pack(w[src])
+    b = bias.detach().float()[src].contiguous() if bias is not None else None
+    return PackedWeight(packed, b, inner, packed.shape[1], geglu=True)
+
+
+def pack_conv3x3(weight, bias=None):
+    """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8."""
+    w = weight.detach().float()
+    cout, cin = w.shape[0], w.shape[1]
+    cin_p = _round_up(cin, 8)
+    wp = torch.zeros(cout, 3, 3, cin_p, dtype=torch.float32, device=w.device)
+    wp[..., :cin] = w.permute(0, 2, 3, 1)
+    packed = _pad_pack(wp.reshape(cout, 9 * cin_p))
+    b = bias.detach().float().contiguous() if bias is not None else None
+    return PackedWeight(packed, b, cout, packed.shape[1], cin=cin_p)
+
+
+# ----------------------------------------------------------------------------- GEMM family
+
+
+def _auto_split_k(m, n_w, k):
+    tiles = math.ceil(m / 128) * math.ceil(n_w / 128)
+    nk = k // _BK
+    if tiles >= 200 or nk < 8:
+        return 1
+    return max(1, min(512 // tiles, nk // 4, 16))
+
+
+def _run_gemm(a, what):
+    hip.check(hip.lib().sdmi_gemm(C.byref(a), _stream()), what)
+
+
+def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m):
+    a.W = pw.w.data_ptr()
+    a.bias = pw.bias.data_ptr() if (bias_on and pw.bias is not None) else None
+    a.N = pw.n_out
+    a.K = pw.k
+    a.geglu = 1 if pw.geglu else 0
+    a.act = act
+    a.out_kind = out_kind
+    a.alpha = alpha
+    a.batch = 1
+    a.out = out.data_ptr()
+    if out_kind == 2:
+        a.ld_out = 0
+    else:
+        a.ld_out = out.stride(-2)
+    a.rows_per_batch = rows_per_batch or 0
+    if emb is not None:
+        # may be a column slice of a wider table: only the innermost stride must be 1
+        if not emb.is_cuda or emb.dtype != torch.float32 or emb.stride(-1) != 1:
+            raise hip.SdmiError("emb: expected a device fp32 matrix with unit inner stride")
+        a.emb = emb.data_ptr()
+        a.ld_emb = emb.stride(0)
+    if res is not None:
+        _require(res, BF16, "res")
+        a.res = res.data_ptr()
+        a.ld_res = res.shape[-1]
+    n_w = pw.n_out * (2 if pw.geglu else 1)
+    sk = _auto_split_k(m, n_w, pw.k)
+    if sk > 1:
+        nbytes = hip.lib().sdmi_gemm_workspace_bytes(m, n_w, sk)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+        a.workspace = ws.data_ptr()
+        a.workspace_bytes = nbytes
+        a.split_k = sk
+        return ws
+    a.split_k = 1
+    return None
+
+
+def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=BF16, alpha=1.0, bias=True):
+    """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat)."""
+    _require(x, BF16, "x")
+    k1 = x.shape[-1]
+    m = x.numel() // k1
+    a = hip.GemmArgs()
+    a.mode = 0
+    a.A = x.data_ptr()
+    a.lda = k1
+    a.M = m
+    if x2 is not None:
+        _require(x2, BF16, "x2")
+        a.A2 = x2.data_ptr()
+        a.lda2 = x2.shape[-1]
+        a.k_split = k1
+        if k1 + x2.shape[-1] != pw.k:
+            raise hip.SdmiError("linear: concat width does not match the packed weight")
+    elif k1 != pw.k:
+        raise hip.SdmiError(f"linear: K mismatch ({k1} vs packed {pw.k})")
+    out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
+    keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype == BF16 else 1, alpha, m)
+    _run_gemm(a, "sdmi_gemm(linear)")
+    del keep
+    return out
+
+
+def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False):
+    """3x3 conv, pad 1, on an NHWC bf16 image [B, H, W, Cin]; optional fused nearest-x2 input gather,
+    time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC bf16, or fp32 NCHW."""
+    _require(x, BF16, "x")
+    b, h, w, cin = x.shape
+    if cin != pw.cin:
+        raise hip.SdmiError(f"conv3x3: Cin mismatch ({cin} vs packed {pw.cin})")
+    hl, wl = (2 * h, 2 * w) if upsample else (h, w)
+    ho, wo = (hl + 2 - 3) // stride + 1, (wl + 2 - 3) // stride + 1
+    a = hip.GemmArgs()
+    a.mode = 1
+    a.A = x.data_ptr()
+    a.H, a.W_in, a.Cin, a.Ho, a.Wo = h, w, cin, ho, wo
+    a.stride = stride
+    a.upsample = 1 if upsample else 0
+    m = b * ho * wo
+    a.M = m
+    if out_nchw_f32:
+        out = torch.empty(b, pw.n_out, ho, wo, dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty(b, ho, wo, pw.n_out, dtype=BF16, device=x.device)
+    keep = _fill_common(a, pw, out, True, emb, ho * wo, res, 0, 2 if out_nchw_f32 else 0, 1.0, m)
+    _run_gemm(a, "sdmi_gemm(conv3x3)")
+    del keep
+    return out
+
+
+def gemm_nt_batched(a_mat, b_mat, out_dtype, alpha=1.0, bias_rows=None):
+    """Batched out[z] = alpha * a[z] @ b[z]^T (+ bias per ROW).  a: [Z, M, K], b: [Z, N, K] bf16 (Z may be
+    1-broadcast for a).  Used for the VAE single-head attention products."""
+    _require(a_mat, BF16, "a")
+    _require(b_mat, BF16, "b")
+    z = b_mat.shape[0]
+    m, k = a_mat.shape[-2], a_mat.shape[-1]
+    n = b_mat.shape[-2]
+    if k % _BK or b_mat.shape[-1] != k or n % _BN:
+        raise hip.SdmiError("gemm_nt_batched: K must be a multiple of 64 and N a multiple of 128")
+    out = torch.empty(z, m, n, dtype=out_dtype, device=a_mat.device)
+    g = hip.GemmArgs()
+    g.mode = 0
+    g.A, g.lda, g.M = a_mat.data_ptr(), k, m
+    g.W, g.N, g.K = b_mat.data_ptr(), n, k
+    g.out, g.ld_out = out.data_ptr(), n
+    g.out_kind = 0 if out_dtype == BF16 else 1
+    g.alpha = alpha
+    g.batch = z
+    g.split_k = 1
+    g.stride_a = 0 if a_mat.shape[0] == 1 else m * k
+    g.stride_w = n * k
+    g.stride_out = m * n
+    if bias_rows is not None:
+        _require(bias_rows, torch.float32, "bias_rows")
+        g.bias = bias_rows.data_ptr()
+        g.bias_per_row = 1
+    _run_gemm(g, "sdmi_gemm(batched)")
+    return out
+
+
+# ----------------------------------------------------------------------------- norms
+
+
+def groupnorm(x1, gamma, beta, eps, silu, x2=None):
+    """GroupNorm(32)(+SiLU) over NHWC bf16; x2 = second half of a channel concat (read in place)."""
+    _require(x1, BF16, "x1")
+    _require(x2, BF16, "x2")
+    _require(gamma, torch.float32, "gamma")
+    _require(beta, torch.float32, "beta")
+    b = x1.shape[0]
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    hw = x1.numel() // (b * c1)
+    out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=BF16, device=x1.device)
+    nbytes = hip.lib().sdmi_groupnorm_workspace_bytes(b, hw)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x1.device)
+    hip.check(hip.lib().sdmi_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b, hw, eps,
+                                       1 if silu else 0, _p(ws), nbytes, _stream()), "sdmi_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _require(x, BF16, "x")
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    hip.check(hip.lib().sdmi_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, _stream()),
+              "sdmi_layernorm")
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+
+
+def attention_d64(q, k, v, heads, nb, nq, nk, scale):
+    """q: [nb*nq, >=heads*64] (may be a column slice of a fused qkv buffer), k/v: [nb*nk, ...].
+    Row strides are taken from the tensors; the innermost stride must be 1."""
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dtype != BF16 or not t.is_cuda or t.stride(-1) != 1:
+            raise hip.SdmiError(f"attention: bad {name}")
+    out = torch.empty(nb * nq, heads * 64, dtype=BF16, device=q.device)
+    hip.check(hip.lib().sdmi_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
+                                           v.stride(0), out.stride(0), scale, _stream()), "sdmi_attention_d64")
+    return out
+
+
+def softmax_rows(s):
+    """fp32 [R, Ccols] -> bf16 row softmax."""
+    _require(s, torch.float32, "s")
+    rows, cols = s.numel() // s.shape[-1], s.shape[-1]
+    out = torch.empty(s.shape, dtype=BF16, device=s.device)
+    hip.check(hip.lib().sdmi_softmax_rows(_p(s), _p(out), rows, cols, cols, cols, _stream()), "sdmi_softmax_rows")
+    return out
+
+
+def softmax_cols(st):
+    """fp32 [Z, R, Ccols] -> bf16, softmax over the ROW index of every column."""
+    _require(st, torch.float32, "st")
+    z, rows, cols = st.shape
+    out = torch.empty(st.shape, dtype=BF16, device=st.device)
+    nbytes = hip.lib().sdmi_softmax_cols_scratch_bytes(z, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=st.device)
+    hip.check(hip.lib().sdmi_softmax_cols(_p(st), _p(out), _p(ws), z, rows, cols, _stream()), "sdmi_softmax_cols")
+    return out
+
+
+# ----------------------------------------------------------------------------- edges
+
+
+def nchw_to_nhwc(x, cpad=None, scale=1.0):
+    """fp32 [B, C, H, W] -> bf16 [B, H, W, Cpad]."""
+    _require(x, torch.float32, "x")
+    b, c, h, w = x.shape
+    cpad = cpad or _round_up(c, 8)
+    out = torch.empty(b, h, w, cpad, dtype=BF16, device=x.device)
+    hip.check(hip.lib().sdmi_nchw_f32_to_nhwc_bf16(_p(x), _p(out), b, c, cpad, h * w, scale, _stream()),
+              "sdmi_nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def to_bf16(x):
+    _require(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    hip.check(hip.lib().sdmi_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "sdmi_f32_to_bf16")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    _require(t, torch.int64, "t")
+    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    hip.check(hip.lib().sdmi_timestep_embedding(_p(t), _p(out), t.shape[0], dim, max_period, _stream()),
+              "sdmi_timestep_embedding")
+    return out
+
+
+def ddim_step(x, model_out, a_t, a_prev, sigma_t, sqrt_one_minus_a_t, guidance_scale=1.0, cfg=False, v_param=False,
+              noise=None, want_pred_x0=False):
+    _require(x, torch.float32, "x")
+    _require(model_out, torch.float32, "model_out")
+    _require(noise, torch.float32, "noise")
+    n = x.numel()
+    if model_out.numel() != (2 * n if cfg else n):
+        raise hip.SdmiError("ddim_step: model_out has the wrong size")
+    x_prev = torch.empty_like(x)
+    pred = torch.empty_like(x) if want_pred_x0 else None
+    hip.check(hip.lib().sdmi_ddim_step(_p(x), _p(model_out), _p(noise), _p(x_prev), _p(pred), n, 1 if cfg else 0,
+                                       guidance_scale, a_t, a_prev, sigma_t, sqrt_one_minus_a_t, 1 if v_param else 0,
+                                       _stream()), "sdmi_ddim_step")
+    return x_prev, pred
+
+
+def image_to_u8(x):
+    """fp32 NCHW in [-1, 1] -> uint8 NHWC."""
+    _require(x, torch.float32, "x")
+    b, c, h, w = x.shape
+    out = torch.empty(b, h, w, c, dtype=torch.uint8, device=x.device)
+    hip.check(hip.lib().sdmi_image_to_u8(_p(x), _p(out), b, c, h * w, _stream()), "sdmi_image_to_u8")
+    return out

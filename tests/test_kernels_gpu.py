@@ -1,0 +1,314 @@
+"""GPU parity of every HIP kernel behind the C ABI against a plain fp32 PyTorch statement of the same op
+on the same bf16-rounded inputs (floating-point kernels: tolerance written per test; the bf16 output
+rounding alone is 2^-9 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def _ops():
+    from stablediffusion_amd import ops
+    return ops
+
+
+def rnd(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def q(x):
+    """Round to bf16 and back: what the kernel actually sees."""
+    return x.to(BF16).float()
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| - the per-tensor relative error of SURVEY.md §8(d)."""
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12)).item()
+
+
+# ----------------------------------------------------------------------------- MFMA layout probes
+
+
+def test_gemm_identity_layout(dev):
+    """A = I against an ASYMMETRIC W exposes any row/col swap in the fragment or C/D maps (exact in bf16)."""
+    ops = _ops()
+    n, k = 128, 128
+    w = (torch.arange(n, device=dev)[:, None] * 3 + torch.arange(k, device=dev)[None, :] * 5 % 7).float() % 64
+    x = torch.eye(k, device=dev)
+    pw = ops.pack_linear(w)
+    out = ops.linear(x.to(BF16), pw, out_dtype=torch.float32)
+    assert torch.equal(out, w.t().contiguous())
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 320, 320), (77, 1280, 1024), (128, 128, 64), (1000, 320, 1280),
+                                   (4096, 640, 640), (130, 4, 320), (300, 200, 192)])
+def test_linear_bias(dev, m, n, k):
+    ops = _ops()
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    pw = ops.pack_linear(w, b)
+    out = ops.linear(x.to(BF16), pw)
+    ref = F.linear(q(x), q(w), b)
+    assert out.shape == (m, n)
+    assert rel_err(out, ref) < 6e-3
+    out32 = ops.linear(x.to(BF16), pw, out_dtype=torch.float32)
+    assert rel_err(out32, ref) < 2e-5 * math.sqrt(k) + 1e-5
+
+
+def test_linear_epilogues(dev):
+    ops = _ops()
+    m, n, k = 512, 640, 320
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    res = rnd((m, n), dev, 4)
+    emb = rnd((4, 2 * n), dev, 5)[:, n:]   # strided rows, 4 "batches" of 128 rows
+    pw = ops.pack_linear(w, b)
+    out = ops.linear(x.to(BF16), pw, res=res.to(BF16), emb=emb, rows_per_batch=128, out_dtype=torch.float32)
+    ref = F.linear(q(x), q(w), b) + emb.repeat_interleave(128, dim=0) + q(res)
+    assert rel_err(out, ref) < 1e-4
+    out = ops.linear(x.to(BF16), pw, act=1, out_dtype=torch.float32)
+    assert rel_err(out, F.silu(F.linear(q(x), q(w), b))) < 1e-4
+    out = ops.linear(x.to(BF16), pw, alpha=0.25, bias=False, out_dtype=torch.float32)
+    assert rel_err(out, 0.25 * F.linear(q(x), q(w))) < 1e-4
+
+
+def test_linear_concat(dev):
+    """Two-pointer A == torch.cat on the channel dim (openai_model.py:1010 feeding a 1x1 skip conv)."""
+    ops = _ops()
+    m, k1, k2, n = 256, 640, 320, 320
+    x1, x2 = rnd((m, k1), dev, 1), rnd((m, k2), dev, 2)
+    w, b = rnd((n, k1 + k2), dev, 3, 0.03), rnd((n,), dev, 4)
+    out = ops.linear(x1.to(BF16), ops.pack_linear(w, b), x2=x2.to(BF16), out_dtype=torch.float32)
+    ref = F.linear(torch.cat([q(x1), q(x2)], -1), q(w), b)
+    assert rel_err(out, ref) < 1e-4
+
+
+def test_geglu(dev):
+    ops = _ops()
+    m, c = 300, 320
+    x = rnd((m, c), dev, 1)
+    w, b = rnd((8 * c, c), dev, 2, c ** -0.5), rnd((8 * c,), dev, 3)
+    out = ops.linear(x.to(BF16), ops.pack_geglu(w, b), out_dtype=torch.float32)
+    a, gate = F.linear(q(x), q(w), b).chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    assert out.shape == (m, 4 * c)
+    assert rel_err(out, ref) < 1e-4
+
+
+def test_split_k(dev):
+    ops = _ops()
+    m, n, k = 128, 1280, 11520
+    assert ops._auto_split_k(m, n, k) > 1
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    res = rnd((m, n), dev, 4)
+    out = ops.linear(x.to(BF16), ops.pack_linear(w, b), res=res.to(BF16), out_dtype=torch.float32)
+    ref = F.linear(q(x), q(w), b) + q(res)
+    assert rel_err(out, ref) < 1e-4
+    # GEGLU through split-K
+    w2, b2 = rnd((2560, 2560), dev, 5, 0.02), rnd((2560,), dev, 6)
+    x2 = rnd((64, 2560), dev, 7)
+    assert ops._auto_split_k(64, 2560, 2560) > 1
+    out = ops.linear(x2.to(BF16), ops.pack_geglu(w2, b2), out_dtype=torch.float32)
+    a, gate = F.linear(q(x2), q(w2), b2).chunk(2, dim=-1)
+    assert rel_err(out, a * F.gelu(gate)) < 1e-4
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,ups", [
+    (2, 16, 16, 64, 128, 1, False), (1, 32, 32, 320, 320, 1, False), (2, 16, 16, 128, 128, 2, False),
+    (2, 8, 8, 64, 64, 1, True), (2, 12, 20, 192, 96, 1, False), (1, 9, 7, 64, 32, 2, False),
+    (2, 8, 8, 1280, 1280, 1, False),
+])
+def test_conv3x3(dev, b, h, w, cin, cout, stride, ups):
+    ops = _ops()
+    x = rnd((b, cin, h, w), dev, 1)
+    wt, bias = rnd((cout, cin, 3, 3), dev, 2, (9 * cin) ** -0.5), rnd((cout,), dev, 3)
+    x_nhwc = q(x).permute(0, 2, 3, 1).contiguous().to(BF16)
+    out = ops.conv3x3(x_nhwc, ops.pack_conv3x3(wt, bias), stride=stride, upsample=ups)
+    xi = F.interpolate(q(x), scale_factor=2, mode="nearest") if ups else q(x)
+    ref = F.conv2d(xi, q(wt), bias, stride=stride, padding=1)
+    assert out.shape == (b, ref.shape[2], ref.shape[3], cout)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 6e-3
+
+
+def test_conv3x3_edges(dev):
+    """conv_in (4 -> C, channels padded to 8), conv_out (C -> 4, fp32 NCHW out) and emb + residual epilogue."""
+    ops = _ops()
+    x = rnd((2, 4, 16, 16), dev, 1)
+    wt, bias = rnd((64, 4, 3, 3), dev, 2, 1 / 6), rnd((64,), dev, 3)
+    x8 = ops.nchw_to_nhwc(x)
+    assert x8.shape == (2, 16, 16, 8)
+    assert torch.equal(x8[..., :4].float(), q(x).permute(0, 2, 3, 1))
+    assert x8[..., 4:].abs().max().item() == 0
+    out = ops.conv3x3(x8, ops.pack_conv3x3(wt, bias))
+    assert rel_err(out.permute(0, 3, 1, 2), F.conv2d(q(x), q(wt), bias, padding=1)) < 6e-3
+
+    h = rnd((2, 64, 16, 16), dev, 4)
+    w2, b2 = rnd((4, 64, 3, 3), dev, 5, 1 / 24), rnd((4,), dev, 6)
+    h_nhwc = q(h).permute(0, 2, 3, 1).contiguous().to(BF16)
+    out = ops.conv3x3(h_nhwc, ops.pack_conv3x3(w2, b2), out_nchw_f32=True)
+    assert out.shape == (2, 4, 16, 16) and out.dtype == torch.float32
+    assert rel_err(out, F.conv2d(q(h), q(w2), b2, padding=1)) < 1e-4
+
+    w3, b3 = rnd((64, 64, 3, 3), dev, 7, 1 / 24), rnd((64,), dev, 8)
+    emb, res = rnd((2, 64), dev, 9), rnd((2, 16, 16, 64), dev, 10)
+    out = ops.conv3x3(h_nhwc, ops.pack_conv3x3(w3, b3), emb=emb, res=res.to(BF16))
+    ref = F.conv2d(q(h), q(w3), b3, padding=1) + emb[:, :, None, None] + q(res).permute(0, 3, 1, 2)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 6e-3
+
+
+def test_batched_gemm(dev):
+    ops = _ops()
+    z, m, n, k = 3, 256, 256, 512
+    a, b = rnd((z, m, k), dev, 1), rnd((z, n, k), dev, 2)
+    out = ops.gemm_nt_batched(a.to(BF16), b.to(BF16), torch.float32, alpha=0.5)
+    ref = 0.5 * torch.einsum("zmk,znk->zmn", q(a), q(b))
+    assert rel_err(out, ref) < 1e-4
+    a1 = rnd((1, m, k), dev, 3)
+    bias = rnd((m,), dev, 4)
+    out = ops.gemm_nt_batched(a1.to(BF16), b.to(BF16), BF16, bias_rows=bias)
+    ref = torch.einsum("mk,znk->zmn", q(a1[0]), q(b)) + bias[None, :, None]
+    assert rel_err(out, ref) < 6e-3
+
+
+# ----------------------------------------------------------------------------- norms
+
+
+@pytest.mark.parametrize("b,hw,c1,c2,silu,eps", [
+    (2, 1024, 320, 0, True, 1e-5), (2, 256, 640, 320, True, 1e-5), (1, 64, 1280, 1280, True, 1e-5),
+    (2, 4096, 128, 0, True, 1e-6), (1, 100, 1280, 640, False, 1e-6), (3, 70000, 128, 0, True, 1e-6),
+    (2, 16, 320, 0, False, 1e-6),
+])
+def test_groupnorm(dev, b, hw, c1, c2, silu, eps):
+    ops = _ops()
+    x1 = rnd((b, hw, c1), dev, 1) * 2 + 0.7
+    x2 = rnd((b, hw, c2), dev, 2) * 0.5 - 1.0 if c2 else None
+    c = c1 + c2
+    gamma, beta = 1 + 0.2 * rnd((c,), dev, 3), 0.1 * rnd((c,), dev, 4)
+    out = ops.groupnorm(x1.to(BF16), gamma, beta, eps, silu, x2=x2.to(BF16) if c2 else None)
+    xin = q(x1) if not c2 else torch.cat([q(x1), q(x2)], -1)
+    ref = F.group_norm(xin.permute(0, 2, 1), 32, gamma, beta, eps)   # [b, c, hw]
+    if silu:
+        ref = F.silu(ref)
+    assert out.shape == (b, hw, c)
+    assert rel_err(out.permute(0, 2, 1), ref) < 6e-3
+
+
+@pytest.mark.parametrize("rows,c", [(1000, 320), (77, 640), (4096, 1280), (3, 1024)])
+def test_layernorm(dev, rows, c):
+    ops = _ops()
+    x = rnd((rows, c), dev, 1) * 3 + 1
+    gamma, beta = 1 + 0.2 * rnd((c,), dev, 2), 0.1 * rnd((c,), dev, 3)
+    out = ops.layernorm(x.to(BF16), gamma, beta, 1e-5)
+    ref = F.layer_norm(q(x), (c,), gamma, beta, 1e-5)
+    assert rel_err(out, ref) < 6e-3
+
+
+# ----------------------------------------------------------------------------- attention
+
+
+def _attn_ref(qq, kk, vv, nb, heads, nq, nk, scale):
+    def split(t, n):
+        return t.reshape(nb, n, heads, 64).permute(0, 2, 1, 3)
+    s = torch.einsum("bhid,bhjd->bhij", split(qq, nq), split(kk, nk)) * scale
+    o = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), split(vv, nk))
+    return o.permute(0, 2, 1, 3).reshape(nb * nq, heads * 64)
+
+
+@pytest.mark.parametrize("nb,heads,nq,nk", [(2, 5, 1024, 1024), (2, 20, 64, 64), (2, 10, 256, 77), (1, 3, 16, 16),
+                                            (1, 2, 144, 144), (1, 5, 4096, 77), (1, 1, 200, 333)])
+def test_attention(dev, nb, heads, nq, nk):
+    ops = _ops()
+    c = heads * 64
+    qq, kk, vv = rnd((nb * nq, c), dev, 1), rnd((nb * nk, c), dev, 2), rnd((nb * nk, c), dev, 3)
+    out = ops.attention_d64(qq.to(BF16), kk.to(BF16), vv.to(BF16), heads, nb, nq, nk, 0.125)
+    ref = _attn_ref(q(qq), q(kk), q(vv), nb, heads, nq, nk, 0.125)
+    assert rel_err(out, ref) < 1e-2
+
+
+def test_attention_fused_qkv_and_spike(dev):
+    """q/k/v as column slices of one [M, 3C] buffer; one key spiked so the running max jumps mid-sequence
+    (forces the online-softmax rescale path with a large factor)."""
+    ops = _ops()
+    nb, heads, n = 1, 2, 512
+    c = heads * 64
+    qkv = rnd((nb * n, 3 * c), dev, 1)
+    qkv[300, c:2 * c] *= 12.0      # key 300 dominates for aligned queries
+    qkv[5, :c] = qkv[300, c:2 * c] / 12.0
+    buf = qkv.to(BF16)
+    out = ops.attention_d64(buf[:, :c], buf[:, c:2 * c], buf[:, 2 * c:], heads, nb, n, n, 0.125)
+    f = buf.float()
+    ref = _attn_ref(f[:, :c], f[:, c:2 * c], f[:, 2 * c:], nb, heads, n, n, 0.125)
+    assert rel_err(out, ref) < 1e-2
+
+
+def test_softmax_rows_cols(dev):
+    ops = _ops()
+    s = rnd((2, 300, 512), dev, 1) * 4
+    p = ops.softmax_rows(s)
+    assert rel_err(p, s.softmax(-1)) < 6e-3
+    pt = ops.softmax_cols(s)
+    assert rel_err(pt, s.softmax(1)) < 6e-3
+
+
+# ----------------------------------------------------------------------------- edges
+
+
+def test_timestep_embedding(dev):
+    ops = _ops()
+    t = torch.tensor([1, 21, 500, 981], device=dev, dtype=torch.int64)
+    out = ops.timestep_embedding(t, 320)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / half)
+    args = t[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert (out.float() - ref).abs().max().item() < 1e-2   # bf16 storage of values in [-1, 1] + fp32 sin/cos of ~1e3 rad
+
+
+@pytest.mark.parametrize("v_param,cfg", [(False, True), (True, True), (False, False)])
+def test_ddim_step(dev, v_param, cfg):
+    ops = _ops()
+    x = rnd((2, 4, 8, 8), dev, 1)
+    mo = rnd((4 if cfg else 2, 4, 8, 8), dev, 2)
+    noise = rnd((2, 4, 8, 8), dev, 3)
+    a_t, a_prev, sig = 0.5, 0.6, 0.1
+    s1m = math.sqrt(1 - a_t)
+    xp, p0 = ops.ddim_step(x, mo, a_t, a_prev, sig, s1m, guidance_scale=9.0, cfg=cfg, v_param=v_param, noise=noise,
+                           want_pred_x0=True)
+    o = mo[:2] + 9.0 * (mo[2:] - mo[:2]) if cfg else mo
+    if v_param:
+        e_t = math.sqrt(a_t) * o + s1m * x
+        pred = math.sqrt(a_t) * x - s1m * o
+    else:
+        e_t = o
+        pred = (x - s1m * e_t) / math.sqrt(a_t)
+    ref = math.sqrt(a_prev) * pred + math.sqrt(1 - a_prev - sig ** 2) * e_t + sig * noise
+    assert rel_err(xp, ref) < 1e-5
+    assert rel_err(p0, pred) < 1e-5
+
+
+def test_image_to_u8_and_cast(dev):
+    ops = _ops()
+    x = rnd((2, 3, 16, 16), dev, 1)
+    out = ops.image_to_u8(x)
+    ref = (torch.clamp((x + 1) / 2, 0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert (out.int() - ref.int()).abs().max().item() <= 1
+    y = rnd((77 * 1024 + 3,), dev, 2)
+    assert torch.equal(ops.to_bf16(y), y.to(BF16))
+
+
+def test_errors_are_loud(dev):
+    """Error behaviour of the boundary: Python exceptions, never a silent fallback."""
+    ops = _ops()
+    from stablediffusion_amd import hip
+    x = rnd((8, 320), dev, 1)
+    pw = ops.pack_linear(rnd((64, 320), dev, 2))
+    with pytest.raises(hip.SdmiError):
+        ops.linear(x, pw)                      # fp32 activations
+    with pytest.raises(hip.SdmiError):
+        ops.linear(x.cpu().to(BF16), pw)       # host tensor: no CPU fallback
+    with pytest.raises(hip.SdmiError):
+        ops.linear(rnd((8, 128), dev, 3).to(BF16), pw)   # K mismatch
