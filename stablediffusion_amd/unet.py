@@ -1,0 +1,443 @@
+"""UNetModel on the HIP path - host-side mirror of the reference's
+ldm/modules/diffusion/openai_model.py (UNetModel :457-1018, ResBlock :151-304, DownSample :119-148,
+UpSample :67-116) and ldm/modules/attention.py (SpatialTransformer :170-265, BasicTransformerBlock
+:462-537, CrossAttention :268-380, FeedForward/GEGLU :72-121).
+
+Same constructor keywords, same parameter names (state-dict compatible with the reference; upstream
+spellings are accepted on load), same ``forward(x, time_steps, context)`` contract.  The module tree
+only *holds* the fp32 master parameters; ``forward`` runs a static list of HIP kernel calls over
+bf16 NHWC activations and pre-packed bf16 weights:
+
+  * every conv / linear is one ``sdmi_gemm`` launch with its bias, time-embedding add, GEGLU and
+    residual add fused in the epilogue; UpSample's nearest-x2 and the skip-connection
+    ``torch.cat`` (openai_model.py:1010) are read in place (gather / two pointers);
+  * q|k|v projections of self-attention are one GEMM; cross-attention K/V of all 16 transformer
+    blocks are one GEMM on the context, cached per context tensor (they depend on the prompt only,
+    attention.py:312-313); the 22 ResBlock time-embedding projections are one GEMM per call;
+  * NCHW<->(hw)c rearranges of SpatialTransformer (attention.py:249,260) vanish: NHWC *is* [B*HW, C].
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class GroupNorm32(nn.GroupNorm):
+    """Parameter holder for the reference's fp32-cast GroupNorm (ldm/utils.py:267-278)."""
+
+
+# ------------------------------------------------------------------ parameter containers (no compute)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, channels, embedding_channels, dropout, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(),
+                                       nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.embedding_layers = nn.Sequential(nn.SiLU(), nn.Linear(embedding_channels, self.out_channels))
+        self.out_layers = nn.Sequential(GroupNorm32(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+
+
+class DownSample(nn.Module):
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.operation = nn.Conv2d(channels, self.out_channels, 3, stride=2, padding=1)
+
+
+class UpSample(nn.Module):
+    def __init__(self, channels, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.conv = nn.Conv2d(channels, self.out_channels, 3, padding=1)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4, dropout=0.0):
+        super().__init__()
+        inner = int(dim * mult)
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim))
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = context_dim if context_dim is not None else query_dim
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head, dropout)
+        self.feed_forward = FeedForward(dim, dropout=dropout)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head, dropout)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None, use_linear=False):
+        super().__init__()
+        if context_dim is not None and not isinstance(context_dim, (list, tuple)):
+            context_dim = [context_dim] * depth
+        self.in_channels = in_channels
+        self.n_heads, self.d_head = n_heads, d_head
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.use_linear = use_linear
+        if use_linear:
+            self.project_in = nn.Linear(in_channels, inner)
+            self.proj_out = zero_module(nn.Linear(in_channels, inner))   # sic: argument order as in attention.py:224
+        else:
+            self.project_in = nn.Conv2d(in_channels, inner, 1)
+            self.proj_out = zero_module(nn.Conv2d(inner, in_channels, 1))
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, dropout, context_dim[d]) for d in range(depth)])
+
+
+class TimestepEmbeddingSequential(nn.Sequential):
+    """Container only (openai_model.py:38-64); dispatch happens in UNetModel._run_block."""
+
+
+# Upstream (Stability-AI) parameter spellings -> the reference's
+_UPSTREAM_RENAMES = [
+    ("time_embed.", "time_embedding."), ("label_emb.", "label_embedding."), (".emb_layers.", ".embedding_layers."),
+    (".op.", ".operation."), (".proj_in.", ".project_in."), (".ff.net.", ".feed_forward.net."),
+]
+
+
+def rename_upstream_keys(state_dict):
+    out = {}
+    for k, v in state_dict.items():
+        for a, b in _UPSTREAM_RENAMES:
+            if a in k or k.startswith(a):
+                k = k.replace(a, b)
+        out[k] = v
+    return out
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, use_bf16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_up_sample=-1, use_scale_shift_norm=False, res_block_updown=False,
+                 use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True, disable_self_attentions=None,
+                 num_attention_blocks=None, disable_middle_self_attn=False, use_linear_in_transformer=False,
+                 adm_in_channels=None):
+        super().__init__()
+        if use_spatial_transformer:
+            assert context_dim is not None, "use_spatial_transformer needs context_dim"
+        if context_dim is not None:
+            assert use_spatial_transformer, "context_dim needs use_spatial_transformer"
+            if not isinstance(context_dim, (int, list, tuple)):   # OmegaConf ListConfig (openai_model.py:539-542)
+                context_dim = list(context_dim)
+        if num_heads == -1:
+            assert num_head_channels != -1, "set num_heads or num_head_channels"
+        if num_head_channels == -1:
+            assert num_heads != -1, "set num_heads or num_head_channels"
+        unsupported = {
+            "dims != 2": dims != 2, "num_classes": num_classes is not None,
+            "use_scale_shift_norm": use_scale_shift_norm, "res_block_updown": res_block_updown,
+            "not use_spatial_transformer": not use_spatial_transformer, "not conv_resample": not conv_resample,
+            "n_embed": n_embed is not None, "disable_self_attentions": disable_self_attentions is not None,
+            "num_attention_blocks": num_attention_blocks is not None, "disable_middle_self_attn": disable_middle_self_attn,
+        }
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"HIP UNetModel: options outside the SD2 hot path are not built: {bad}")
+
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = len(channel_mult) * [num_res_blocks] if isinstance(num_res_blocks, int) \
+            else list(num_res_blocks)
+        if len(self.num_res_blocks) != len(channel_mult):
+            raise ValueError("num_res_blocks must be an int or have one entry per channel_mult level")
+        self.attention_resolutions = list(attention_resolutions)
+        self.dropout = dropout
+        self.channel_mult = tuple(channel_mult)
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint      # read by callers (txt2img.py:373); a no-op for inference
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+        self.dtype = torch.bfloat16 if use_bf16 else self.dtype
+        self.compute_dtype = torch.bfloat16       # what the HIP kernels store activations/weights in
+        self.num_heads, self.num_head_channels = num_heads, num_head_channels
+
+        ted = model_channels * 4
+        self.time_embedding = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+
+        def heads_for(ch):
+            if num_head_channels == -1:
+                return num_heads, ch // num_heads
+            return ch // num_head_channels, num_head_channels
+
+        def make_st(ch):
+            nh, dh = heads_for(ch)
+            return SpatialTransformer(ch, nh, dh, depth=transformer_depth, context_dim=context_dim,
+                                      use_linear=use_linear_in_transformer)
+
+        self.input_blocks = nn.ModuleList(
+            [TimestepEmbeddingSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                layers = [ResBlock(ch, ted, dropout, out_channels=mult * model_channels)]
+                ch = mult * model_channels
+                if ds in self.attention_resolutions:
+                    layers.append(make_st(ch))
+                self.input_blocks.append(TimestepEmbeddingSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbeddingSequential(DownSample(ch, out_channels=ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbeddingSequential(ResBlock(ch, ted, dropout), make_st(ch),
+                                                        ResBlock(ch, ted, dropout))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(self.num_res_blocks[level] + 1):
+                ich = chans.pop()
+                layers = [ResBlock(ch + ich, ted, dropout, out_channels=model_channels * mult)]
+                ch = model_channels * mult
+                if ds in self.attention_resolutions:
+                    layers.append(make_st(ch))
+                if level and i == self.num_res_blocks[level]:
+                    layers.append(UpSample(ch, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbeddingSequential(*layers))
+        # repair B4: the final conv maps model_channels -> the constructor's out_channels
+        self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(),
+                                 zero_module(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
+        self._pack = None
+        self._ctx_cache = None
+
+    # ------------------------------------------------------------------ state dict / packing
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self._pack = None
+        return super().load_state_dict(rename_upstream_keys(state_dict), strict=strict, **kw)
+
+    def _apply(self, fn, *a, **kw):
+        self._pack = None      # .cuda() / .to(): packed weights follow the parameters
+        self._ctx_cache = None
+        return super()._apply(fn, *a, **kw)
+
+    def invalidate_packed(self):
+        """Call after mutating parameters in place (packed bf16 copies are rebuilt on the next forward)."""
+        self._pack = None
+        self._ctx_cache = None
+
+    def _res_blocks(self):
+        for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+            for layer in blk:
+                if isinstance(layer, ResBlock):
+                    yield layer
+
+    def _transformers(self):
+        for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+            for layer in blk:
+                if isinstance(layer, SpatialTransformer):
+                    yield layer
+
+    @torch.no_grad()
+    def _build_pack(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise ops.hip.SdmiError("HIP UNetModel.forward needs the model on a GPU (model.cuda()); "
+                                    "there is no CPU fallback")
+        pk = {}
+        f32 = lambda t: t.detach().float().contiguous()
+        te = self.time_embedding
+        pk["te0"] = ops.pack_linear(te[0].weight, te[0].bias)
+        pk["te2"] = ops.pack_linear(te[2].weight, te[2].bias)
+        # all ResBlock embedding projections as one [sum Cout, 4*mc] GEMM
+        rbs = list(self._res_blocks())
+        pk["emb_all"] = ops.pack_linear_cat([r.embedding_layers[1].weight for r in rbs],
+                                            [r.embedding_layers[1].bias for r in rbs])
+        off = 0
+        for r in rbs:
+            e = {"emb_off": off}
+            off += r.out_channels
+            e["gn1"] = (f32(r.in_layers[0].weight), f32(r.in_layers[0].bias))
+            e["conv1"] = ops.pack_conv3x3(r.in_layers[2].weight, r.in_layers[2].bias)
+            e["gn2"] = (f32(r.out_layers[0].weight), f32(r.out_layers[0].bias))
+            e["conv2"] = ops.pack_conv3x3(r.out_layers[3].weight, r.out_layers[3].bias)
+            if isinstance(r.skip_connection, nn.Conv2d):
+                if r.skip_connection.kernel_size != (1, 1):
+                    raise NotImplementedError("3x3 skip_connection (use_conv=True) is outside the SD2 path")
+                e["skip"] = ops.pack_linear(r.skip_connection.weight, r.skip_connection.bias)
+            pk[id(r)] = e
+        # cross-attention K/V of every transformer block, one GEMM on the context
+        kv_w = []
+        kv_off = 0
+        for st in self._transformers():
+            e = {"norm": (f32(st.norm.weight), f32(st.norm.bias)),
+                 "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias),
+                 "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias), "blocks": []}
+            for tb in st.transformer_blocks:
+                c = tb.attn1.to_q.weight.shape[0]
+                be = {
+                    "ln1": (f32(tb.norm1.weight), f32(tb.norm1.bias)),
+                    "ln2": (f32(tb.norm2.weight), f32(tb.norm2.bias)),
+                    "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
+                    "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight]),
+                    "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias),
+                    "q2": ops.pack_linear(tb.attn2.to_q.weight),
+                    "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias),
+                    "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias),
+                    "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias),
+                    "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
+                }
+                if tb.attn1.dim_head != 64:
+                    raise NotImplementedError("sdmi_attention_d64 is built for head dim 64 (SD2: num_head_channels=64)")
+                kv_w += [tb.attn2.to_k.weight, tb.attn2.to_v.weight]
+                kv_off += 2 * c
+                e["blocks"].append(be)
+            pk[id(st)] = e
+        pk["kv_all"] = ops.pack_linear_cat(kv_w)
+        for blk in list(self.input_blocks) + list(self.output_blocks):
+            for layer in blk:
+                if isinstance(layer, nn.Conv2d):
+                    pk[id(layer)] = ops.pack_conv3x3(layer.weight, layer.bias)
+                elif isinstance(layer, DownSample):
+                    pk[id(layer)] = ops.pack_conv3x3(layer.operation.weight, layer.operation.bias)
+                elif isinstance(layer, UpSample):
+                    pk[id(layer)] = ops.pack_conv3x3(layer.conv.weight, layer.conv.bias)
+        pk["out_gn"] = (f32(self.out[0].weight), f32(self.out[0].bias))
+        pk["out_conv"] = ops.pack_conv3x3(self.out[2].weight, self.out[2].bias)
+        self._pack = pk
+        return pk
+
+    # ------------------------------------------------------------------ forward pieces
+
+    def _context_kv(self, pk, context):
+        key = (context.data_ptr(), tuple(context.shape), context._version, context.dtype)
+        if self._ctx_cache is not None and self._ctx_cache[0] == key:
+            return self._ctx_cache[1]
+        ctx = context if context.dtype == BF16 else ops.to_bf16(context.float().contiguous())
+        kv = ops.linear(ctx.reshape(-1, ctx.shape[-1]), pk["kv_all"])     # [B*Nk, sum 2C]
+        self._ctx_cache = (key, kv, context)   # keep `context` alive so data_ptr stays unique
+        return kv
+
+    def _res_block(self, pk, r, h, skip, emb_all):
+        e = pk[id(r)]
+        emb = emb_all[:, e["emb_off"]:e["emb_off"] + r.out_channels]
+        n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-5, True, x2=skip)
+        h1 = ops.conv3x3(n1, e["conv1"], emb=emb)
+        n2 = ops.groupnorm(h1, e["gn2"][0], e["gn2"][1], 1e-5, True)
+        if "skip" in e:
+            sk = ops.linear(h, e["skip"], x2=skip)
+        else:
+            assert skip is None
+            sk = h
+        return ops.conv3x3(n2, e["conv2"], res=sk)
+
+    def _transformer(self, pk, st, h, kv, nk):
+        e = pk[id(st)]
+        b, hh, ww, c = h.shape
+        n = hh * ww
+        xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False)
+        t = ops.linear(xn.reshape(b * n, c), e["pin"])
+        for be in e["blocks"]:
+            ci, heads = be["c"], be["heads"]
+            y = ops.layernorm(t, *be["ln1"])
+            qkv = ops.linear(y, be["qkv1"])
+            a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
+            t = ops.linear(a, be["o1"], res=t)
+            y = ops.layernorm(t, *be["ln2"])
+            q2 = ops.linear(y, be["q2"])
+            ko = be["kv_off"]
+            a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
+            t = ops.linear(a, be["o2"], res=t)
+            y = ops.layernorm(t, *be["ln3"])
+            g = ops.linear(y, be["geglu"])
+            t = ops.linear(g, be["ff2"], res=t)
+        out = ops.linear(t, e["pout"], res=h.reshape(b * n, c))
+        return out.reshape(b, hh, ww, c)
+
+    def _run_block(self, pk, blk, h, skip, emb_all, kv, nk):
+        for layer in blk:
+            if isinstance(layer, ResBlock):
+                h = self._res_block(pk, layer, h, skip, emb_all)
+                skip = None
+            elif isinstance(layer, SpatialTransformer):
+                h = self._transformer(pk, layer, h, kv, nk)
+            elif isinstance(layer, DownSample):
+                h = ops.conv3x3(h, pk[id(layer)], stride=2)
+            elif isinstance(layer, UpSample):
+                h = ops.conv3x3(h, pk[id(layer)], upsample=True)
+            elif isinstance(layer, nn.Conv2d):
+                h = ops.conv3x3(h, pk[id(layer)])
+            else:
+                raise NotImplementedError(type(layer))
+        return h
+
+    @torch.no_grad()
+    def forward(self, x, time_steps=None, context=None, label=None, timesteps=None, y=None, **kwargs):
+        """x [B, C, h, w] (fp32/fp16/bf16 NCHW), time_steps int64 [B], context [B, Nk, context_dim]
+        -> eps / v prediction, same shape and dtype as x (openai_model.py:940-1018)."""
+        time_steps = time_steps if time_steps is not None else timesteps
+        label = label if label is not None else y
+        assert (label is not None) == (self.num_classes is not None), \
+            "must specify label if and only if the model is class-conditional"
+        assert time_steps is not None and context is not None
+        pk = self._pack or self._build_pack()
+        bsz = x.shape[0]
+        t = time_steps.to(device=x.device, dtype=torch.int64).contiguous()
+        if t.dim() == 0:
+            t = t.expand(bsz).contiguous()
+        # time path: sinusoid -> Linear -> SiLU -> Linear -> (SiLU, shared by all ResBlocks) -> 22 projections
+        te = ops.timestep_embedding(t, self.model_channels)
+        e1 = ops.linear(te, pk["te0"], act=1)
+        e2 = ops.linear(e1, pk["te2"], act=1)
+        emb_all = ops.linear(e2, pk["emb_all"], out_dtype=torch.float32)
+        kv = self._context_kv(pk, context)
+        nk = context.shape[1]
+
+        h = ops.nchw_to_nhwc(x.float().contiguous())
+        hs = []
+        for blk in self.input_blocks:
+            h = self._run_block(pk, blk, h, None, emb_all, kv, nk)
+            hs.append(h)
+        h = self._run_block(pk, self.middle_block, h, None, emb_all, kv, nk)
+        for blk in self.output_blocks:
+            h = self._run_block(pk, blk, h, hs.pop(), emb_all, kv, nk)
+        n = ops.groupnorm(h, pk["out_gn"][0], pk["out_gn"][1], 1e-5, True)
+        out = ops.conv3x3(n, pk["out_conv"], out_nchw_f32=True)
+        return out.type(x.dtype)

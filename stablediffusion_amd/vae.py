@@ -1,0 +1,284 @@
+"""AutoencoderKL decode path on the HIP kernels - host-side mirror of the reference's
+ldm/models/autoencoder.py (AutoencoderKL :14-93) and ldm/modules/diffusion/model.py (Decoder :282-411,
+ResnetBlock :414-476, AttnBlock :479-528, UpSample :110-142).
+
+Constructor keywords accept both the reference's spellings (``dd_config/loss_config/embedding_dim``,
+``channels/out_channels``) and the YAML's / upstream's (``ddconfig/lossconfig/embed_dim``, ``ch/out_ch``)
+- repair B12.  Parameter names follow the reference (``up.N.up_sample.conv``; upstream's ``upsample`` is
+accepted on load).  ``decode`` is restated (absent from the reference): post_quant_conv -> Decoder.
+
+``vae_attn`` selects what the single-head mid attention computes:
+  "reference": literally model.py:519-523 - W = softmax_j(q_i.k_j/sqrt(C)) but V contracted over the
+               QUERY index: out[:, j] = sum_i v[:, i] W[i, j]   (the parity default)
+  "standard":  upstream's softmax(QK^T) V   (what real SD weights need)
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .util import instantiate_from_config
+
+BF16 = torch.bfloat16
+
+
+def _gn(c):
+    return nn.GroupNorm(32, c, eps=1e-6, affine=True)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = _gn(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.norm2 = _gn(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
+
+
+class AttnBlock(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = _gn(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, 1)
+        self.k = nn.Conv2d(in_channels, in_channels, 1)
+        self.v = nn.Conv2d(in_channels, in_channels, 1)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, 1)
+
+
+class UpSample(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
+
+
+def _pad_rows(t, mult):
+    """[Z, R, K] -> rows padded with zeros to a multiple of `mult` (only tiny test shapes need it)."""
+    r = t.shape[1]
+    rp = (r + mult - 1) // mult * mult
+    if rp == r:
+        return t
+    out = torch.zeros(t.shape[0], rp, t.shape[2], dtype=t.dtype, device=t.device)
+    out[:, :r] = t
+    return out
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, channels=None, out_channels=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions,
+                 dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False,
+                 tanh_out=False, use_linear_attn=False, attn_type="vanilla", ch=None, out_ch=None,
+                 vae_attn="reference", **ignorekwargs):
+        super().__init__()
+        channels = channels if channels is not None else ch
+        out_channels = out_channels if out_channels is not None else out_ch
+        if channels is None or out_channels is None:
+            raise TypeError("Decoder needs channels/ch and out_channels/out_ch")
+        if use_linear_attn or attn_type not in ("vanilla",) or not resamp_with_conv or give_pre_end or tanh_out:
+            raise NotImplementedError("HIP Decoder: only the SD2 configuration (vanilla attention, conv resample) is built")
+        self.channels = channels
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.vae_attn = vae_attn
+        block_in = channels * ch_mult[-1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = channels * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.up_sample = UpSample(block_in)
+                curr_res *= 2
+            self.up.insert(0, up)
+        self.norm_out = _gn(block_in)              # repair B5
+        self.conv_out = nn.Conv2d(block_in, out_channels, 3, padding=1)
+        self._pack = None
+
+    def _apply(self, fn, *a, **kw):
+        self._pack = None
+        return super()._apply(fn, *a, **kw)
+
+    def invalidate_packed(self):
+        self._pack = None
+
+    @torch.no_grad()
+    def _build_pack(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise ops.hip.SdmiError("HIP Decoder.forward needs the model on a GPU; there is no CPU fallback")
+        f32 = lambda t: t.detach().float().contiguous()
+        pk = {}
+        for m in self.modules():
+            if isinstance(m, ResnetBlock):
+                e = {"gn1": (f32(m.norm1.weight), f32(m.norm1.bias)), "conv1": ops.pack_conv3x3(m.conv1.weight, m.conv1.bias),
+                     "gn2": (f32(m.norm2.weight), f32(m.norm2.bias)), "conv2": ops.pack_conv3x3(m.conv2.weight, m.conv2.bias)}
+                if hasattr(m, "nin_shortcut"):
+                    e["skip"] = ops.pack_linear(m.nin_shortcut.weight, m.nin_shortcut.bias)
+                pk[id(m)] = e
+            elif isinstance(m, AttnBlock):
+                c = m.in_channels
+                pk[id(m)] = {
+                    "gn": (f32(m.norm.weight), f32(m.norm.bias)),
+                    "q": ops.pack_linear(m.q.weight, m.q.bias), "k": ops.pack_linear(m.k.weight, m.k.bias),
+                    # V^T = Wv . Xn^T needs Wv as the (unpadded-row) A operand and its bias per row
+                    "wv": m.v.weight.detach().reshape(c, c).to(BF16).contiguous()[None], "bv": f32(m.v.bias),
+                    "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias),
+                }
+            elif isinstance(m, UpSample):
+                pk[id(m)] = ops.pack_conv3x3(m.conv.weight, m.conv.bias)
+        pk["conv_in"] = ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias)
+        pk["norm_out"] = (f32(self.norm_out.weight), f32(self.norm_out.bias))
+        pk["conv_out"] = ops.pack_conv3x3(self.conv_out.weight, self.conv_out.bias)
+        self._pack = pk
+        return pk
+
+    def _resnet(self, pk, m, h):
+        e = pk[id(m)]
+        n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-6, True)
+        h1 = ops.conv3x3(n1, e["conv1"])
+        n2 = ops.groupnorm(h1, e["gn2"][0], e["gn2"][1], 1e-6, True)
+        sk = ops.linear(h, e["skip"]) if "skip" in e else h
+        return ops.conv3x3(n2, e["conv2"], res=sk)
+
+    def _attn(self, pk, m, h):
+        e = pk[id(m)]
+        b, hh, ww, c = h.shape
+        n = hh * ww
+        if c % 64:
+            raise NotImplementedError("VAE attention needs channels % 64 == 0")
+        hn = ops.groupnorm(h, e["gn"][0], e["gn"][1], 1e-6, False).reshape(b, n, c)
+        q = ops.linear(hn, e["q"])
+        k = ops.linear(hn, e["k"])
+        scale = float(int(c) ** (-0.5))
+        hn_p = _pad_rows(hn, 128)
+        npad = hn_p.shape[1]
+        vt = ops.gemm_nt_batched(e["wv"], hn_p, BF16, bias_rows=e["bv"])       # [b, c, npad]: V^T (+bias per channel)
+        if npad != n:
+            vt[:, :, n:] = 0
+        if self.vae_attn == "reference":
+            # ST[j, i] = scale * k_j . q_i ; PT[j, i] = W[i, j] (softmax over j) ; O[j, :] = sum_i PT[j, i] V[i, :]
+            st = ops.gemm_nt_batched(k, _pad_rows(q, 128), torch.float32, alpha=scale)[:, :, :n].contiguous() \
+                if npad != n else ops.gemm_nt_batched(k, q, torch.float32, alpha=scale)
+            pt = ops.softmax_cols(st)
+        elif self.vae_attn == "standard":
+            st = ops.gemm_nt_batched(q, _pad_rows(k, 128), torch.float32, alpha=scale)[:, :, :n].contiguous() \
+                if npad != n else ops.gemm_nt_batched(q, k, torch.float32, alpha=scale)
+            pt = ops.softmax_rows(st)
+        else:
+            raise ValueError(f"vae_attn must be 'reference' or 'standard', got {self.vae_attn!r}")
+        if n % 64:
+            raise NotImplementedError("VAE attention needs h*w % 64 == 0")
+        if npad != n:   # K (= token count) of the last product must match between P and V^T
+            ptp = torch.zeros(b, n, npad, dtype=BF16, device=h.device)
+            ptp[:, :, :n] = pt
+            pt = ptp
+        cp = (c + 127) // 128 * 128
+        vt_p = _pad_rows(vt, 128) if cp != c else vt
+        o = ops.gemm_nt_batched(pt, vt_p, BF16)[:, :, :c]
+        if cp != c:
+            o = o.contiguous()
+        out = ops.linear(o.reshape(b * n, c), e["proj"], res=h.reshape(b * n, c))
+        return out.reshape(b, hh, ww, c)
+
+    @torch.no_grad()
+    def forward(self, z, scale=1.0):
+        """z: fp32 NCHW latent [B, z_channels, h, w] (or an already-NHWC bf16 tensor from decode()) ->
+        fp32 NCHW image [B, out_channels, 8h, 8w] (model.py:371-411)."""
+        pk = self._pack or self._build_pack()
+        h = z if z.dtype == BF16 else ops.nchw_to_nhwc(z.float().contiguous(), scale=scale)
+        h = ops.conv3x3(h, pk["conv_in"])
+        h = self._resnet(pk, self.mid.block_1, h)
+        h = self._attn(pk, self.mid.attn_1, h)
+        h = self._resnet(pk, self.mid.block_2, h)
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = self._resnet(pk, lvl.block[i_block], h)
+                if len(lvl.attn) > 0:
+                    h = self._attn(pk, lvl.attn[i_block], h)
+            if i_level != 0:
+                h = ops.conv3x3(h, pk[id(lvl.up_sample)], upsample=True)
+        n = ops.groupnorm(h, pk["norm_out"][0], pk["norm_out"][1], 1e-6, True)
+        return ops.conv3x3(n, pk["conv_out"], out_nchw_f32=True)
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, dd_config=None, loss_config=None, embedding_dim=None, ckpt_path=None, ignore_keys=(),
+                 image_key="image", colorize_nlabels=None, monitor=None, ema_decay=None, learn_log_var=False,
+                 ddconfig=None, lossconfig=None, embed_dim=None, vae_attn="reference"):
+        super().__init__()
+        dd_config = dict(dd_config if dd_config is not None else ddconfig)
+        loss_config = loss_config if loss_config is not None else lossconfig
+        embedding_dim = embedding_dim if embedding_dim is not None else embed_dim
+        assert dd_config["double_z"], "double_z must be set"
+        self.image_key = image_key
+        self.learn_log_var = learn_log_var
+        self.embedding_dim = embedding_dim
+        # The encoder half (img2img / training only) is outside the denoising hot path.
+        self.encoder = None
+        self.decoder = Decoder(vae_attn=vae_attn, **dd_config)
+        self.loss = instantiate_from_config(loss_config) if loss_config is not None else None
+        self.post_quant_conv = nn.Conv2d(embedding_dim, dd_config["z_channels"], 1)
+        if monitor is not None:
+            self.monitor = monitor
+        self._pq = None
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=list(ignore_keys))
+
+    def init_from_ckpt(self, path, ignore_keys=()):
+        sd = torch.load(path, map_location="cpu", weights_only=True)["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                print(f"Deleting key {k} from state_dict.")
+                del sd[k]
+        self.load_state_dict(sd, strict=False)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = {k.replace(".upsample.", ".up_sample."): v for k, v in state_dict.items()}
+        self._pq = None
+        self.decoder._pack = None
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _apply(self, fn, *a, **kw):
+        self._pq = None
+        return super()._apply(fn, *a, **kw)
+
+    def encode(self, x):
+        raise NotImplementedError("AutoencoderKL.encode: the VAE encoder is outside the denoising hot path")
+
+    @torch.no_grad()
+    def decode(self, z, scale=1.0):
+        """post_quant_conv (1x1, autoencoder.py:54) then Decoder.  `scale` multiplies z first
+        (decode_first_stage passes 1/scale_factor so the division is fused into the layout kernel)."""
+        if self._pq is None:
+            w = self.post_quant_conv.weight.detach().float()
+            zc, ed = w.shape[0], w.shape[1]
+            zp = (zc + 7) // 8 * 8
+            wp = torch.zeros(zp, (ed + 7) // 8 * 8, device=w.device)
+            wp[:zc, :ed] = w.reshape(zc, ed)
+            bp = torch.zeros(zp, device=w.device)
+            bp[:zc] = self.post_quant_conv.bias.detach().float()
+            self._pq = ops.pack_linear(wp, bp)     # output channels padded to 8 (zeros) for conv_in's 16-byte loads
+        h = ops.nchw_to_nhwc(z.float().contiguous(), cpad=self._pq.k, scale=scale)   # [B, h, w, 64], zero padded
+        h = ops.linear(h, self._pq)                                                    # [B, h, w, 8]
+        return self.decoder(h)
+
+    def forward(self, z):
+        return self.decode(z)
