@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of the latent-diffusion hot path on MI355X (contract: see the task statement).
+
+A "step" is one pass of the hot path over one batch: a full 50-step DDIM sampling with classifier-free
+guidance (50 UNet forwards at batch 2B) + decode_first_stage + uint8 conversion of B images of 512x512
+(BASELINE.json configs[2] per-GPU slice: SD2-base, 64x64 latent, batch 8 per GPU; with --batch 1 it is
+configs[1]).  Inputs (weights, x_T, text embeddings) are resident in HBM before the timed region.
+Weak scaling: every rank runs its own batch; the only cross-GPU traffic is the final uint8 image gather.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SD2_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+                num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64, use_spatial_transformer=True,
+                use_linear_in_transformer=True, transformer_depth=1, context_dim=1024, legacy=False,
+                use_checkpoint=True, use_bf16=True)
+SD2_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                    ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+# algorithmic FLOPs (2 per MAC), SURVEY.md §8(d) / BASELINE.md §4
+UNET_GFLOP = {32: 181.1, 64: 804.3, 96: 2149.1}
+DEC_GFLOP = {32: 622.2, 64: 2514.5, 96: 5754.3}
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+
+
+def build_model(dev, parameterization="eps"):
+    from stablediffusion_amd import instantiate_from_config
+    cfg = {"target": "ldm.models.diffusion.ddpm.LatentDiffusion", "params": {
+        "linear_start": 0.00085, "linear_end": 0.0120, "timesteps": 1000, "conditioning_key": "crossattn",
+        "scale_factor": 0.18215, "use_ema": False, "parameterization": parameterization, "image_size": 64, "channels": 4,
+        "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(SD2_UNET)},
+        "first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL", "params": {
+            "embed_dim": 4, "ddconfig": dict(SD2_DDCONFIG), "lossconfig": {"target": "torch.nn.Identity"}}},
+        "cond_stage_config": "__is_unconditional__", "force_null_conditioning": True}}
+    with torch.device("meta"):
+        model = instantiate_from_config(cfg)
+    model.model.diffusion_model.to_empty(device=dev)
+    model.first_stage_model.to_empty(device=dev)
+    # random-init weights of the SD2 architecture, generated on the device (a function of the parameter name);
+    # zero-initialised tensors get values too
+    with torch.no_grad():
+        for name, p in list(model.model.named_parameters()) + list(model.first_stage_model.named_parameters()):
+            g = torch.Generator(device=dev).manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+            if name.endswith("bias"):
+                p.normal_(0, 0.05, generator=g)
+            elif p.dim() == 1:
+                p.normal_(1.0, 0.1, generator=g)
+            else:
+                p.normal_(0, (p[0].numel()) ** -0.5, generator=g)
+    model.register_schedule(None, "linear", 1000, 0.00085, 0.0120)
+    for name, buf in list(model.named_buffers(recurse=False)):
+        setattr(model, name, buf.to(dev))
+    return model.eval()
+
+
+def cpu_baseline(model, h, ddim_steps):
+    """The oracle (CPU fp32 restatement, oracle/) timed on this box's host cores on a bounded sample of the
+    same workload: two CFG UNet steps (batch 2) at the benchmark latent size + one 1-image decode, scaled to
+    images/sec = 1 / (ddim_steps * t_step + t_decode)."""
+    from oracle import model as OM
+    from oracle import sampler as OS
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    usd = {k: v.detach().float().cpu() for k, v in model.model.diffusion_model.state_dict().items()}
+    vsd = {k: v.detach().float().cpu() for k, v in model.first_stage_model.state_dict().items()}
+    cfg = {k: v for k, v in SD2_UNET.items()}
+    x = torch.randn(2, 4, h, h)
+    ctx = torch.randn(2, 77, 1024)
+    t = torch.full((2,), 501, dtype=torch.long)
+    with torch.no_grad():
+        OM.unet_forward(usd, cfg, x[:1, :, :16, :16].contiguous(), t[:1], ctx[:1])     # page in / warm up
+        t0 = time.perf_counter()
+        n_steps = 2
+        for _ in range(n_steps):
+            OM.unet_forward(usd, cfg, x, t, ctx)
+        t_step = (time.perf_counter() - t0) / n_steps
+        t0 = time.perf_counter()
+        OS.decode_first_stage(vsd, SD2_DDCONFIG, x[:1], 0.18215)
+        t_dec = time.perf_counter() - t0
+    return {"value": 1.0 / (ddim_steps * t_step + t_dec), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{n_steps} CFG UNet steps (batch 2, {h}x{h} latent) + 1 VAE decode ({8 * h}^2) of the fp32 CPU "
+                      f"oracle; scaled as 1/({ddim_steps}*t_step + t_decode)",
+            "unet_step_s": t_step, "decode_s": t_dec}
+
+
+def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T):
+    """Dominant kernel = sdmi_gemm_kernel<1> (implicit-GEMM conv3x3, 52% of UNet and 99% of decoder FLOPs).
+    achieved = algorithmic FLOPs per launch / average launch duration, both averaged over the launch
+    population of ONE benchmark step (ddim_steps UNet forwards at batch 2B + one decode of B images);
+    durations from HIP events recorded on the launch stream around every launch."""
+    from stablediffusion_amd import ops
+    dev = x_T.device
+    c_in = torch.cat([uc, c]).contiguous()
+    ts = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+    x_in = torch.cat([x_T, x_T])
+
+    def collect(fn):
+        ops.TRACE = []
+        fn()
+        torch.cuda.synchronize()
+        tr, ops.TRACE = ops.TRACE, None
+        return [(k, f, e0.elapsed_time(e1) * 1e-3, sk) for k, f, e0, e1, sk in tr]
+
+    collect(lambda: model.apply_model(x_in, ts, c_in))       # warm
+    un = collect(lambda: model.apply_model(x_in, ts, c_in))
+    de = collect(lambda: model.decode_first_stage(x_T))
+    out = {}
+    for kind in ("conv3x3", "linear"):
+        u = [(f, t) for k, f, t, _ in un if k == kind]
+        d = [(f, t) for k, f, t, _ in de if k == kind]
+        fl = ddim_steps * sum(f for f, _ in u) + sum(f for f, _ in d)
+        tm = ddim_steps * sum(t for _, t in u) + sum(t for _, t in d)
+        n = ddim_steps * len(u) + len(d)
+        out[kind] = (fl, tm, n)
+    fl, tm, n = out["conv3x3"]
+    lf, lt, ln = out["linear"]
+    return {"bound": "mfma", "achieved": fl / tm / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": fl / tm / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "sdmi_gemm_kernel<1> (implicit-GEMM conv3x3, bf16 MFMA 16x16x32)",
+            "flops_per_launch": fl / n, "avg_launch_us": tm / n * 1e6, "launches_per_step": n,
+            "note": "launch time includes the split-K reduce kernel where split-K is used",
+            "linear_kernel": {"kernel": "sdmi_gemm_kernel<0>", "achieved": lf / lt / 1e12, "frac": lf / lt / 1e12 / MFMA_PEAK_TFLOPS,
+                              "flops_per_launch": lf / ln, "avg_launch_us": lt / ln * 1e6, "launches_per_step": ln}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (UNet batch is 2x with CFG)")
+    ap.add_argument("--latent", type=int, default=64, help="latent side: 64 = 512^2, 96 = 768^2")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--scale", type=float, default=9.0)
+    ap.add_argument("--parameterization", default="eps", choices=["eps", "v"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from stablediffusion_amd.ddim import DDIMSampler
+    from stablediffusion_amd import ops
+    model = build_model(dev, args.parameterization)
+    sampler = DDIMSampler(model)
+    B, h = args.batch, args.latent
+    # synthetic inputs of SURVEY.md §8(d): per-rank latents, shared "prompt" embeddings
+    x_T = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    c = torch.randn(B, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(dev)
+    uc = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(99)).expand(B, -1, -1).contiguous().to(dev)
+
+    def one_step():
+        samples, _ = sampler.sample(S=args.ddim_steps, batch_size=B, shape=[4, h, h], conditioning=c, verbose=False,
+                                    unconditional_guidance_scale=args.scale, unconditional_conditioning=uc, eta=0.0,
+                                    x_T=x_T)
+        img = model.decode_first_stage(samples)
+        u8 = ops.image_to_u8(img)
+        if world > 1:       # the only cross-GPU traffic: final image gather to rank 0 (RCCL)
+            gl = [torch.empty_like(u8) for _ in range(world)] if rank == 0 else None
+            dist.gather(u8, gl, dst=0)
+        return u8
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert out.shape == (B, 8 * h, 8 * h, 3) and torch.isfinite(out.float()).all()
+
+    images = world * B * args.steps
+    value = images / dt
+    flop_per_image = (2 * args.ddim_steps * UNET_GFLOP.get(h, 0) + DEC_GFLOP.get(h, 0)) * 1e9
+    result = {
+        "metric": "images/sec (node) SD2-base 512^2 50-step DDIM; UNet step ms", "value": value, "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SD2 v2-inference UNet+VAE random-init, {8 * h}^2 ({h}x{h} latent), batch {B}/GPU, "
+                               f"{args.ddim_steps} DDIM steps + CFG (UNet batch {2 * B}), decode + uint8; "
+                               f"BASELINE.json configs[{1 if B == 1 else 2}]",
+                   "global_batch": world * B, "latent": h, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world}",
+                   "parameterization": args.parameterization},
+        "unet_step_ms": None,
+        "effective_tflops_per_gpu": value / world * flop_per_image / 1e12 if flop_per_image else None,
+        "mfma_frac_end_to_end": value / world * flop_per_image / 1e12 / MFMA_PEAK_TFLOPS if flop_per_image else None,
+    }
+    # UNet step ms (one CFG-batched forward), HIP events on the launch stream
+    c_in = torch.cat([uc, c]).contiguous()
+    ts = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+    x_in = torch.cat([x_T, x_T])
+    model.apply_model(x_in, ts, c_in)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        model.apply_model(x_in, ts, c_in)
+    e1.record()
+    torch.cuda.synchronize()
+    result["unet_step_ms"] = e0.elapsed_time(e1) / 5
+    e0.record()
+    model.decode_first_stage(x_T)
+    e1.record()
+    torch.cuda.synchronize()
+    result["decode_ms"] = e0.elapsed_time(e1)
+
+    if rank == 0:
+        if not args.no_roofline:
+            result["roofline"] = roofline(model, sampler, B, h, args.ddim_steps, c, uc, x_T)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(model, h, args.ddim_steps)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

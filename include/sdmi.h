@@ -50,7 +50,8 @@ int sdmi_abi_version(void);
  * W is PRE-PACKED by the caller: bf16 [Npad][K], K contiguous, Npad = N_w rounded up to 128,
  * rows >= N_w zero.  K must be a multiple of 64 (pad with zero columns).
  *   mode 0 (linear / 1x1 conv): A is [M, lda] row-major; if A2 != NULL columns [0,k_split) come
- *       from A and [k_split,K) from A2 (row stride lda2); k_split % 64 == 0.
+ *       from A and [k_split,K) from A2 (row stride lda2); k_split % 64 == 0.  If the logical width of A
+ *       is not a multiple of 64, pass it as k_valid: columns [k_valid, K) read as zero.
  *   mode 1 (3x3 conv, pad 1): A is an NHWC image [nb, H, W, Cin]; row m = (b, oy, ox) of the
  *       [nb, Ho, Wo] output; k = (ky*3+kx)*Cin + ci (weights packed in that order); stride 1|2;
  *       upsample=1 reads the input through a nearest x2 gather (logical input 2H x 2W).
@@ -76,6 +77,7 @@ typedef struct sdmi_gemm_args {
     int64_t workspace_bytes;
     int64_t M, N, K;
     int64_t lda, lda2, k_split;
+    int64_t k_valid;                    /* mode 0: columns >= k_valid of A read as zero (0 = K); % 8 == 0 */
     int64_t ld_res, ld_out, ld_emb, rows_per_batch;
     int64_t stride_a, stride_w, stride_out, stride_res;   /* elements, for batch > 1 */
     int32_t mode;

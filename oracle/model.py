@@ -14,6 +14,31 @@ import torch.nn.functional as F
 
 # ----------------------------------------------------------------------------- helpers
 
+# Operand-precision emulation.  None (default) = the reference's plain fp32 arithmetic.  Set to
+# torch.bfloat16 / torch.float16 (use `operand_precision(...)`) to round the two operands of every
+# contraction (conv / linear weights and inputs, attention q, k, v and probabilities) to that type
+# while still accumulating in fp32 - i.e. exactly what an MFMA with 16-bit operands and fp32
+# accumulators computes.  This separates "the kernel is wrong" from "the operand format is coarse".
+OPERAND_DTYPE = None
+
+
+class operand_precision:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global OPERAND_DTYPE
+        self.prev, OPERAND_DTYPE = OPERAND_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global OPERAND_DTYPE
+        OPERAND_DTYPE = self.prev
+
+
+def _q(x):
+    return x if OPERAND_DTYPE is None else x.to(OPERAND_DTYPE).to(x.dtype)
+
+
 
 def _get(sd, *names):
     for n in names:
@@ -28,11 +53,11 @@ def _has(sd, *names):
 
 def _conv(sd, p, x, stride=1):
     w = sd[p + "weight"]
-    return F.conv2d(x, w, sd.get(p + "bias"), stride=stride, padding=w.shape[-1] // 2)
+    return F.conv2d(_q(x), _q(w), sd.get(p + "bias"), stride=stride, padding=w.shape[-1] // 2)
 
 
 def _lin(sd, p, x):
-    return F.linear(x, sd[p + "weight"], sd.get(p + "bias"))
+    return F.linear(_q(x), _q(sd[p + "weight"]), sd.get(p + "bias"))
 
 
 def _gn(sd, p, x, eps):
@@ -83,10 +108,10 @@ def cross_attention(sd, p, x, context, heads):
     def split(t):  # 'b n (h d) -> (b h) n d', attention.py:315
         return t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(b * heads, t.shape[1], d)
 
-    q, k, v = split(q), split(k), split(v)
+    q, k, v = _q(split(q)), _q(split(k)), _q(split(v))
     sim = torch.einsum("bid,bjd->bij", q.float(), k.float()) * (d ** -0.5)   # attention.py:323-325
     sim = sim.softmax(dim=-1)
-    o = torch.einsum("bij,bjd->bid", sim, v)
+    o = torch.einsum("bij,bjd->bid", _q(sim), v)
     o = o.reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, inner)   # attention.py:378
     return _lin(sd, p + "to_out.0.", o)
 
@@ -260,8 +285,9 @@ def vae_attn_block(sd, p, x, mode="reference"):
     q = _conv(sd, p + "q.", h_).reshape(b, c, hh * ww).permute(0, 2, 1)   # b i c
     k = _conv(sd, p + "k.", h_).reshape(b, c, hh * ww)                    # b c j
     v = _conv(sd, p + "v.", h_).reshape(b, c, hh * ww)                    # b c n
+    q, k, v = _q(q), _q(k), _q(v)
     w_ = torch.einsum("bic,bcj->bij", q, k) * (int(c) ** (-0.5))
-    w_ = F.softmax(w_, dim=-1)
+    w_ = _q(F.softmax(w_, dim=-1))
     if mode == "reference":
         o = torch.einsum("bci,bij->bcj", v, w_)
     elif mode == "standard":

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
         }
     }
     const unsigned rowmask = (rvalid[0] ? 1u : 0u) | (rvalid[1] ? 2u : 0u) | (rvalid[2] ? 4u : 0u) | (rvalid[3] ? 8u : 0u);
+    const int64_t k_valid = p.k_valid > 0 ? p.k_valid : p.K;
     const int Hl = p.H << p.upsample, Wl = p.W_in << p.upsample;
     // conv k-state for this thread's chunk: k = kt*64 + lc*8 -> (tap, ci)
     int c_tap = 0, c_ci = 0;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     // global loads stay in flight across the MFMAs of the current tile.
     unsigned okmask = 0;
 #define SDMI_LOAD_A0(I, DST, KK, BASE, LD) \
-    DST = *reinterpret_cast<const uint4*>((BASE) + (rvalid[I] ? a_off[I] * (LD) + (KK) : 0))
+    DST = *reinterpret_cast<const uint4*>((BASE) + ((rvalid[I] && kin_) ? a_off[I] * (LD) + (KK) : 0))
 #define SDMI_LOAD_A1(I, DST, KY, KX, TV)                                                               \
     do {                                                                                               \
         int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                  \
@@ -203,13 +204,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     do {                                                                                               \
         if (MODE == 0) {                                                                               \
             const int64_t k_ = (int64_t)(KT) * BK + lc * 8;                                            \
+            const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */   \
             const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                 \
             const unsigned short* base_ = second_ ? A2 : A;                                            \
             const int64_t ld_ = second_ ? p.lda2 : p.lda;                                              \
             const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                         \
             SDMI_LOAD_A0(0, ra0, kk_, base_, ld_); SDMI_LOAD_A0(1, ra1, kk_, base_, ld_);              \
             SDMI_LOAD_A0(2, ra2, kk_, base_, ld_); SDMI_LOAD_A0(3, ra3, kk_, base_, ld_);              \
-            okmask = rowmask;                                                                          \
+            okmask = kin_ ? rowmask : 0u;                                                              \
         } else {                                                                                       \
             const int ky_ = c_tap / 3, kx_ = c_tap - 3 * ky_;                                          \
             const bool tapvalid_ = c_tap < 9;                                                          \
@@ -397,6 +399,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (a->out_kind != 2 && (a->ld_out % 4 != 0)) return SDMI_ERR_ALIGNMENT;
     if (a->mode == 0) {
         if (a->lda % 8 != 0) return SDMI_ERR_ALIGNMENT;
+        if (a->k_valid < 0 || a->k_valid > a->K || a->k_valid % 8 != 0) return SDMI_ERR_ALIGNMENT;
         if (a->A2 != nullptr) {
             if (a->lda2 % 8 != 0 || a->k_split % BK != 0 || a->k_split <= 0 || a->k_split >= a->K)
                 return SDMI_ERR_ALIGNMENT;

@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("emb", C.c_void_p), ("res", C.c_void_p),
         ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
-        ("lda", C.c_int64), ("lda2", C.c_int64), ("k_split", C.c_int64),
+        ("lda", C.c_int64), ("lda2", C.c_int64), ("k_split", C.c_int64), ("k_valid", C.c_int64),
         ("ld_res", C.c_int64), ("ld_out", C.c_int64), ("ld_emb", C.c_int64), ("rows_per_batch", C.c_int64),
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
         ("mode", C.c_int32),

@@ -115,8 +115,26 @@ def _auto_split_k(m, n_w, k):
     return max(1, min(512 // tiles, nk // 4, 16))
 
 
+# Optional per-launch instrumentation (bench.py's roofline leg): when TRACE is a list, every sdmi_gemm
+# launch appends (kind, algorithmic_flops, start_event, end_event) recorded on the launch stream.
+TRACE = None
+
+
+def _gemm_flops(a):
+    n_w = a.N * (2 if a.geglu else 1)
+    k = 9 * a.Cin if a.mode == 1 else (a.k_valid or a.K)
+    return 2 * a.M * n_w * k * max(a.batch, 1)
+
+
 def _run_gemm(a, what):
+    if TRACE is None:
+        hip.check(hip.lib().sdmi_gemm(C.byref(a), _stream()), what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     hip.check(hip.lib().sdmi_gemm(C.byref(a), _stream()), what)
+    e1.record()
+    TRACE.append(("conv3x3" if a.mode == 1 else "linear", _gemm_flops(a), e0, e1, int(a.split_k)))
 
 
 def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m):
@@ -176,7 +194,9 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
         if k1 + x2.shape[-1] != pw.k:
             raise hip.SdmiError("linear: concat width does not match the packed weight")
     elif k1 != pw.k:
-        raise hip.SdmiError(f"linear: K mismatch ({k1} vs packed {pw.k})")
+        if _round_up(k1, _BK) != pw.k or k1 % 8:
+            raise hip.SdmiError(f"linear: K mismatch ({k1} vs packed {pw.k})")
+        a.k_valid = k1          # K padding of the packed weight: columns past k1 read as zero
     out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
     keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype == BF16 else 1, alpha, m)
     _run_gemm(a, "sdmi_gemm(linear)")

@@ -47,7 +47,7 @@ def test_gemm_identity_layout(dev):
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 320, 320), (77, 1280, 1024), (128, 128, 64), (1000, 320, 1280),
-                                   (4096, 640, 640), (130, 4, 320), (300, 200, 192)])
+                                   (4096, 640, 640), (130, 4, 320), (300, 200, 192), (50, 64, 96), (33, 24, 8)])
 def test_linear_bias(dev, m, n, k):
     ops = _ops()
     x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
