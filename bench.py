@@ -166,7 +166,8 @@ def main():
     sampler = DDIMSampler(model)
     B, h = args.batch, args.latent
     # synthetic inputs of SURVEY.md §8(d): per-rank latents, shared "prompt" embeddings
-    x_T = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    from stablediffusion_amd import dp
+    x_T = dp.shard_latents(world * B, rank, world, (4, h, h), base_seed=1234).to(dev)   # seeds follow the GLOBAL index
     c = torch.randn(B, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(dev)
     uc = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(99)).expand(B, -1, -1).contiguous().to(dev)
 
@@ -176,10 +177,9 @@ def main():
                                     x_T=x_T)
         img = model.decode_first_stage(samples)
         u8 = ops.image_to_u8(img)
-        if world > 1:       # the only cross-GPU traffic: final image gather to rank 0 (RCCL)
-            gl = [torch.empty_like(u8) for _ in range(world)] if rank == 0 else None
-            dist.gather(u8, gl, dst=0)
-        return u8
+        # the only cross-GPU traffic: final image gather to rank 0 (RCCL); a no-op at world == 1
+        allimg = dp.gather_images(u8, world * B, rank, world)
+        return u8 if allimg is None else allimg[:B]
 
     def fence():
         torch.cuda.synchronize()
