@@ -33,12 +33,12 @@ __device__ __forceinline__ uint4 gn_load(const unsigned short* x1, const unsigne
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned short* __restrict__ x1,
                                                               const unsigned short* __restrict__ x2, int C1, int C2,
                                                               int64_t hw, int64_t P, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // [2][C]
+    // LDS: per-(thread row) channel sums, [rows][2][C]; summed in a fixed order afterwards (no atomics, so
+    // the result is bit-reproducible from call to call)
+    extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = C1 + C2, nvec = C >> 3, cpg = C / GN_GROUPS;
     const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * C; i += GN_THREADS) sh[i] = 0.f;
-    __syncthreads();
 
     const int cols = nvec < GN_THREADS ? nvec : GN_THREADS;
     const int rows = GN_THREADS / cols;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
     const int64_t p_begin = (int64_t)slab * P;
     const int64_t p_end = (p_begin + P < hw) ? p_begin + P : hw;
     if (trow < rows) {
+        float* mine = sh + (size_t)trow * 2 * C;
         for (int v = tcol; v < nvec; v += cols) {
             float s[8], ss[8];
 #pragma unroll
@@ -59,15 +60,18 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                atomicAdd(&sh[v * 8 + j], s[j]);
-                atomicAdd(&sh[C + v * 8 + j], ss[j]);
+                mine[v * 8 + j] = s[j];
+                mine[C + v * 8 + j] = ss[j];
             }
         }
     }
     __syncthreads();
     if (tid < GN_GROUPS) {
         float S = 0.f, SS = 0.f;
-        for (int j = 0; j < cpg; ++j) { S += sh[tid * cpg + j]; SS += sh[C + tid * cpg + j]; }
+        for (int r = 0; r < rows; ++r) {
+            const float* rowp = sh + (size_t)r * 2 * C;
+            for (int j = 0; j < cpg; ++j) { S += rowp[tid * cpg + j]; SS += rowp[C + tid * cpg + j]; }
+        }
         const float n = (float)((p_end - p_begin) * cpg);
         const float mean = S / n;
         float m2 = SS - S * mean;
@@ -226,7 +230,9 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)nslab, (unsigned)nb);
     const size_t lds = 2 * (size_t)C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), lds, s, reinterpret_cast<const unsigned short*>(x1),
+    const int nvec_h = C / 8;
+    const int rows_h = GN_THREADS / (nvec_h < GN_THREADS ? nvec_h : GN_THREADS);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), lds * rows_h, s, reinterpret_cast<const unsigned short*>(x1),
                        reinterpret_cast<const unsigned short*>(x2), C1, C2, hw, P, partial);
     SDMI_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(64), 0, s, partial, nslab, eps, stats);

@@ -312,3 +312,17 @@ def test_errors_are_loud(dev):
         ops.linear(x.cpu().to(BF16), pw)       # host tensor: no CPU fallback
     with pytest.raises(hip.SdmiError):
         ops.linear(rnd((8, 128), dev, 3).to(BF16), pw)   # K mismatch
+
+
+def test_kernels_are_deterministic(dev):
+    """Same inputs, two launches, bit-identical outputs (no float atomics anywhere on the path)."""
+    ops = _ops()
+    x = rnd((2, 1024, 320), dev, 1).to(BF16)
+    gamma, beta = 1 + 0.2 * rnd((320,), dev, 3), 0.1 * rnd((320,), dev, 4)
+    assert torch.equal(ops.groupnorm(x, gamma, beta, 1e-5, True), ops.groupnorm(x, gamma, beta, 1e-5, True))
+    w = ops.pack_linear(rnd((1280, 11520), dev, 2, 0.01))
+    a = rnd((128, 11520), dev, 5).to(BF16)
+    assert torch.equal(ops.linear(a, w), ops.linear(a, w))          # split-K path
+    qkv = rnd((1024, 3 * 320), dev, 6).to(BF16)
+    f = lambda: ops.attention_d64(qkv[:, :320], qkv[:, 320:640], qkv[:, 640:], 5, 1, 1024, 1024, 0.125)
+    assert torch.equal(f(), f())
