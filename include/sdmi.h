@@ -13,7 +13,7 @@
  *   - the caller owns and allocates inputs, outputs and workspaces; nothing is allocated or
  *     freed inside (safe under HIP graph capture).
  *   - returns SDMI_OK (0) or a negative sdmi_status; never throws.
- *   - activations are bf16, channels-last: images [B, H, W, C] == token matrices [B*H*W, C].
+ *   - activations are 16-bit (bf16 or f16, `dtype` argument / field), channels-last: images [B, H, W, C] == token matrices [B*H*W, C].
  *   - statistics, logits, accumulators and softmax are fp32.
  */
 #ifndef SDMI_H
@@ -33,6 +33,10 @@ typedef enum sdmi_status {
     SDMI_ERR_WORKSPACE = -3,    /* workspace missing or too small */
     SDMI_ERR_LAUNCH = -4        /* hipLaunchKernel reported an error */
 } sdmi_status;
+
+/* 16-bit storage / MFMA operand type of activations and packed weights.  Mirrors the reference's dtype
+ * policy (openai_model.py:602-603: use_fp16 -> float16, use_bf16 -> bfloat16); both run at the same MFMA rate. */
+typedef enum sdmi_dtype { SDMI_DTYPE_BF16 = 0, SDMI_DTYPE_F16 = 1 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
 int sdmi_abi_version(void);
@@ -84,6 +88,7 @@ typedef struct sdmi_gemm_args {
     int32_t H, W_in, Cin, Ho, Wo, stride, upsample;
     int32_t out_kind, geglu, act, bias_per_row;
     int32_t batch, split_k;
+    int32_t dtype;                      /* sdmi_dtype of A, A2, W, res and of out when out_kind == 0 */
     float alpha;
 } sdmi_gemm_args;
 
@@ -102,14 +107,14 @@ int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
  * ---------------------------------------------------------------------------------------- */
 int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2,
                    const float* gamma, const float* beta, void* out,
-                   int32_t nb, int64_t hw, float eps, int32_t silu,
+                   int32_t nb, int64_t hw, float eps, int32_t silu, int32_t dtype,
                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw);
 
 /* LayerNorm over the last dim C of a bf16 [rows, C] matrix, fp32 statistics, affine.
  * Replaces nn.LayerNorm at attention.py:512-514 (called :525-527).  C % 8 == 0. */
 int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out,
-                   int64_t rows, int32_t C, float eps, void* stream);
+                   int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flash-style multi-head attention, head dim 64, bf16 in/out, fp32 logits + online softmax.
@@ -122,7 +127,7 @@ int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* o
 int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out,
                        int32_t nb, int32_t heads, int32_t Nq, int32_t Nk,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                       float scale, void* stream);
+                       float scale, int32_t dtype, void* stream);
 
 /* Row / column softmax helpers for the VAE single-head attention (model.py:514-523), whose
  * score matrix S is produced by sdmi_gemm (out_kind 1).
@@ -131,24 +136,25 @@ int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out,
  *         ST[j, i] = scale * k_j . q_i, so PT = W^T with W row-normalised over j (model.py:521-523).
  * colstats: fp32 scratch of sdmi_softmax_cols_scratch_bytes(batch, cols) bytes. */
 int sdmi_softmax_rows(const float* S, void* P, int64_t rows, int64_t cols, int64_t ld_s, int64_t ld_p,
-                      void* stream);
+                      int32_t dtype, void* stream);
 int sdmi_softmax_cols(const float* ST, void* PT, float* colstats, int32_t batch, int64_t rows, int64_t cols,
-                      void* stream);
+                      int32_t dtype, void* stream);
 int64_t sdmi_softmax_cols_scratch_bytes(int32_t batch, int64_t cols);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / elementwise kernels at the edges of the path.
  * ---------------------------------------------------------------------------------------- */
-/* fp32 NCHW [nb, C, hw] -> bf16 NHWC [nb, hw, Cpad] (channels >= C zero), value * scale.
+/* fp32 NCHW [nb, C, hw] -> 16-bit (dtype) NHWC [nb, hw, Cpad] (channels >= C zero), value * scale.
  * Entry of UNetModel.forward (openai_model.py:980) and of decode_first_stage (z / scale_factor,
  * configs/stable-diffusion/v2-inference.yaml:17). */
 int sdmi_nchw_f32_to_nhwc_bf16(const float* x, void* out, int32_t nb, int32_t C, int32_t Cpad, int64_t hw,
-                               float scale, void* stream);
-/* fp32 -> bf16 cast of a contiguous buffer (context embeddings, openai_model.py:940 `context`). */
-int sdmi_f32_to_bf16(const float* x, void* out, int64_t n, void* stream);
+                               float scale, int32_t dtype, void* stream);
+/* fp32 -> 16-bit (dtype) cast of a contiguous buffer (context embeddings, openai_model.py:940 `context`). */
+int sdmi_cast_f32(const float* x, void* out, int64_t n, int32_t dtype, void* stream);
 /* Sinusoidal timestep embedding, cos first then sin (ldm/utils.py:301-318, repaired B1/B2):
- * out bf16 [nb, dim]. t is int64 [nb]. dim even. */
-int sdmi_timestep_embedding(const int64_t* t, void* out, int32_t nb, int32_t dim, float max_period, void* stream);
+ * out 16-bit (dtype) [nb, dim]. t is int64 [nb]. dim even. */
+int sdmi_timestep_embedding(const int64_t* t, void* out, int32_t nb, int32_t dim, float max_period, int32_t dtype,
+                            void* stream);
 /* Classifier-free-guidance combine + DDIM update on fp32 NCHW latents (the loop body absent from
  * ldm/models/diffusion/ddim.py:184-249; semantics SURVEY.md §3.2).  model_out holds the UNet output
  * for [uncond batch | cond batch] (2*n elements) when e_uc_first != 0, else n elements.

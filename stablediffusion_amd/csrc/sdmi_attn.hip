@@ -34,13 +34,15 @@ __device__ __forceinline__ uint4 zero_unless(uint4 v, bool ok) {
     return v;
 }
 
-__device__ __forceinline__ bf16x8 cvt8(const f32x16& s, int base) {
-    bf16x8 r;
+template <int DT>
+__device__ __forceinline__ uint4 cvt8(const f32x16& s, int base) {
+    float f[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)s[base + j];
-    return r;
+    for (int j = 0; j < 8; ++j) f[j] = s[base + j];
+    return elem_pack8<DT>(f);
 }
 
+template <int DT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) uint4 lds[4 * TILE_CH];   // K0 K1 V0 V1
     uint4* const Ks = lds;
@@ -59,10 +61,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
     // Q fragments (B operand of S^T = K Q^T): lane (q = lr, half hf), k-step s: Q[q][16s + 8hf .. +7]
     const int qrow = blockIdx.x * QB + wid * 32 + lr;
     const int qrow_c = qrow < p.Nq ? qrow : p.Nq - 1;
-    bf16x8 qf[4];
+    uint4 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Qp + (int64_t)qrow_c * p.ldq + 16 * s + 8 * hf));
+        qf[s] = *reinterpret_cast<const uint4*>(Qp + (int64_t)qrow_c * p.ldq + 16 * s + 8 * hf);
 
     f32x16 o0, o1;
 #pragma unroll
@@ -122,10 +124,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
         for (int s = 0; s < 4; ++s) {
             const int ch = 2 * s + hf;
             const int r0 = lr, r1 = 32 + lr;
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[r0 * 8 + (ch ^ ((r0 >> 1) & 7))]);
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[r1 * 8 + (ch ^ ((r1 >> 1) & 7))]);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+            const uint4 k0 = Kb[r0 * 8 + (ch ^ ((r0 >> 1) & 7))];
+            const uint4 k1 = Kb[r1 * 8 + (ch ^ ((r1 >> 1) & 7))];
+            s0 = mfma32<DT>(k0, qf[s], s0);
+            s1 = mfma32<DT>(k1, qf[s], s1);
         }
         // accumulator register r of block kb holds key t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hf, query lr
         if ((t + 1) * KB > p.Nk) {
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pf = cvt8(kb == 0 ? s0 : s1, 8 * ks);
+                const uint4 pf = cvt8<DT>(kb == 0 ? s0 : s1, 8 * ks);
                 const int key0 = kb * 32 + 16 * ks + 4 * hf + tq;      // row of the first 4x16 block
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
@@ -179,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
                     short8v vv;
                     vv[0] = va[0]; vv[1] = va[1]; vv[2] = va[2]; vv[3] = va[3];
                     vv[4] = vc[0]; vv[5] = vc[1]; vv[6] = vc[2]; vv[7] = vc[3];
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-                    if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
-                    else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+                    const uint4 vf = __builtin_bit_cast(uint4, vv);
+                    if (db == 0) o0 = mfma32<DT>(vf, pf, o0);
+                    else         o1 = mfma32<DT>(vf, pf, o1);
                 }
             }
         }
@@ -197,10 +199,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w0, w1;
-            w0.x = pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv);
-            w0.y = pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            w1.x = pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv);
-            w1.y = pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            w0.x = elem_pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = elem_pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = elem_pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = elem_pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(orow + 8 * g + 4 * hf) = w0;
             *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * hf) = w1;
         }
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
 
 extern "C" int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t heads,
                                   int32_t Nq, int32_t Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                                  float scale, void* stream) {
+                                  float scale, int32_t dtype, void* stream) {
+    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
     if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (nb <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return SDMI_ERR_BAD_ARG;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return SDMI_ERR_ALIGNMENT;
@@ -227,7 +230,10 @@ extern "C" int sdmi_attention_d64(const void* q, const void* k, const void* v, v
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.c = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)((Nq + QB - 1) / QB), (unsigned)(nb * heads));
-    hipLaunchKernelGGL(attn_fwd_d64_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(attn_fwd_d64_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(attn_fwd_d64_kernel<0>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

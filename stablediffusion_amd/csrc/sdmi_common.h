@@ -43,5 +43,56 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
     return v;
 }
 
+// ---- element type policy: DT = 0 bf16, 1 f16 (both 16-bit MFMA operand formats run at the same rate) ----
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+template <int DT> __device__ __forceinline__ float elem_to_f32(unsigned short b) {
+    if constexpr (DT == 0) return bf16_bits_to_f32(b);
+    else return (float)__builtin_bit_cast(_Float16, b);
+}
+template <int DT> __device__ __forceinline__ unsigned short elem_from_f32(float f) {
+    if constexpr (DT == 0) return f32_to_bf16_bits(f);
+    else return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+template <int DT> __device__ __forceinline__ unsigned elem_pack2(float lo, float hi) {
+    return (unsigned)elem_from_f32<DT>(lo) | ((unsigned)elem_from_f32<DT>(hi) << 16);
+}
+template <int DT> __device__ __forceinline__ void elem_unpack8(const uint4& v, float* f) {
+    if constexpr (DT == 0) {
+        unpack_bf16x8(v, f);
+    } else {
+        const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
+    }
+}
+template <int DT> __device__ __forceinline__ uint4 elem_pack8(const float* f) {
+    if constexpr (DT == 0) {
+        return pack_bf16x8(f);
+    } else {
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)f[j];
+        return __builtin_bit_cast(uint4, h);
+    }
+}
+template <int DT> __device__ __forceinline__ void elem_unpack4(const uint2& v, float* f) {
+    f[0] = elem_to_f32<DT>((unsigned short)(v.x & 0xffffu)); f[1] = elem_to_f32<DT>((unsigned short)(v.x >> 16));
+    f[2] = elem_to_f32<DT>((unsigned short)(v.y & 0xffffu)); f[3] = elem_to_f32<DT>((unsigned short)(v.y >> 16));
+}
+template <int DT> __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    if constexpr (DT == 0)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
+    if constexpr (DT == 0)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -4,6 +4,7 @@
 
 namespace {
 
+template <int DT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                            int nb, int C, int Cpad, int64_t hw, float scale) {
     const int nvec = Cpad >> 3;
@@ -21,10 +22,11 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             const int c = v * 8 + j;
             f[j] = c < C ? x[((int64_t)b * C + c) * hw + pix] * scale : 0.f;
         }
-        *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix) * Cpad + v * 8) = pack_bf16x8(f);
+        *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix) * Cpad + v * 8) = elem_pack8<DT>(f);
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
                                                           int64_t n) {
     const int64_t nv = n >> 3;
@@ -32,14 +34,15 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8);
         const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
         float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        *reinterpret_cast<uint4*>(out + i * 8) = pack_bf16x8(f);
+        *reinterpret_cast<uint4*>(out + i * 8) = elem_pack8<DT>(f);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
         const int64_t i = (nv << 3) + threadIdx.x;
-        out[i] = f32_to_bf16_bits(x[i]);
+        out[i] = elem_from_f32<DT>(x[i]);
     }
 }
 
+template <int DT>
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, unsigned short* __restrict__ out, int nb,
                                           int dim, float max_period) {
     const int half = dim >> 1;
@@ -49,8 +52,8 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, unsigne
     // ldm/utils.py:304-314: freq = exp(-ln(max_period) * i / half); [cos | sin]
     const float freq = expf(-logf(max_period) * (float)i / (float)half);
     const float arg = (float)t[b] * freq;
-    out[(int64_t)b * dim + i] = f32_to_bf16_bits(cosf(arg));
-    out[(int64_t)b * dim + half + i] = f32_to_bf16_bits(sinf(arg));
+    out[(int64_t)b * dim + i] = elem_from_f32<DT>(cosf(arg));
+    out[(int64_t)b * dim + half + i] = elem_from_f32<DT>(sinf(arg));
 }
 
 __global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ mo,
@@ -114,6 +117,7 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
     return r;
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, unsigned short* __restrict__ P,
                                                            int64_t cols, int64_t ld_s, int64_t ld_p) {
     __shared__ float sh[4];
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) sum += __expf(s[j] - mx);
     sum = block_reduce(sum, false, sh);
     const float inv = 1.0f / sum;
-    for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) p[j] = f32_to_bf16_bits(__expf(s[j] - mx) * inv);
+    for (int64_t j = threadIdx.x; j < cols; j += blockDim.x) p[j] = elem_from_f32<DT>(__expf(s[j] - mx) * inv);
 }
 
 // column statistics of ST [batch][rows][cols]: thread per column, online (max, sum) over a row range.
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(256) void softmax_colmerge_kernel(const float* __re
     stats[((int64_t)b * 2 + 1) * cols + col] = 1.0f / l;
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void softmax_colapply_kernel(const float* __restrict__ ST, unsigned short* __restrict__ PT,
                                                                const float* __restrict__ stats, int64_t rows,
                                                                int64_t cols) {
@@ -186,8 +191,8 @@ __global__ __launch_bounds__(256) void softmax_colapply_kernel(const float* __re
         const f32x4 m = *reinterpret_cast<const f32x4*>(mrow + c);
         const f32x4 il = *reinterpret_cast<const f32x4*>(irow + c);
         uint2 o;
-        o.x = pack_bf16x2(__expf(v[0] - m[0]) * il[0], __expf(v[1] - m[1]) * il[1]);
-        o.y = pack_bf16x2(__expf(v[2] - m[2]) * il[2], __expf(v[3] - m[3]) * il[3]);
+        o.x = elem_pack2<DT>(__expf(v[0] - m[0]) * il[0], __expf(v[1] - m[1]) * il[1]);
+        o.y = elem_pack2<DT>(__expf(v[2] - m[2]) * il[2], __expf(v[3] - m[3]) * il[3]);
         *reinterpret_cast<uint2*>(p + r * cols + c) = o;
     }
 }
@@ -203,33 +208,49 @@ inline unsigned grid_for(int64_t n, int per_block = 256, int64_t cap = 8192) {
 
 }  // namespace
 
-extern "C" int sdmi_nchw_f32_to_nhwc_bf16(const float* x, void* out, int32_t nb, int32_t C, int32_t Cpad, int64_t hw,
-                                          float scale, void* stream) {
+#define SDMI_DT_CHECK(dt) do { if ((dt) != SDMI_DTYPE_BF16 && (dt) != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG; } while (0)
+
+extern "C" int sdmi_nchw_f32_to_nhwc(const float* x, void* out, int32_t nb, int32_t C, int32_t Cpad, int64_t hw,
+                                     float scale, int32_t dtype, void* stream) {
+    SDMI_DT_CHECK(dtype);
     if (x == nullptr || out == nullptr || nb <= 0 || C <= 0 || hw <= 0) return SDMI_ERR_BAD_ARG;
     if (Cpad < C || Cpad % 8 != 0) return SDMI_ERR_ALIGNMENT;
     const int64_t total = (int64_t)nb * hw * (Cpad / 8);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       x, reinterpret_cast<unsigned short*>(out), nb, C, Cpad, hw, scale);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<1>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, reinterpret_cast<unsigned short*>(out), nb, C, Cpad, hw, scale);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<0>, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           x, reinterpret_cast<unsigned short*>(out), nb, C, Cpad, hw, scale);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }
 
-extern "C" int sdmi_f32_to_bf16(const float* x, void* out, int64_t n, void* stream) {
+extern "C" int sdmi_cast_f32(const float* x, void* out, int64_t n, int32_t dtype, void* stream) {
     if (x == nullptr || out == nullptr || n <= 0) return SDMI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((n + 7) / 8)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<unsigned short*>(out), n);
+    SDMI_DT_CHECK(dtype);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(f32_to_bf16_kernel<1>, dim3(grid_for((n + 7) / 8)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<unsigned short*>(out), n);
+    else
+        hipLaunchKernelGGL(f32_to_bf16_kernel<0>, dim3(grid_for((n + 7) / 8)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<unsigned short*>(out), n);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }
 
 extern "C" int sdmi_timestep_embedding(const int64_t* t, void* out, int32_t nb, int32_t dim, float max_period,
-                                       void* stream) {
+                                       int32_t dtype, void* stream) {
     if (t == nullptr || out == nullptr || nb <= 0 || dim <= 0) return SDMI_ERR_BAD_ARG;
+    SDMI_DT_CHECK(dtype);
     if (dim % 2 != 0) return SDMI_ERR_ALIGNMENT;
     const int half = dim / 2;
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((unsigned)((half + 63) / 64), (unsigned)nb), dim3(64), 0,
-                       reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<unsigned short*>(out), nb, dim,
-                       max_period);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(timestep_embedding_kernel<1>, dim3((unsigned)((half + 63) / 64), (unsigned)nb), dim3(64), 0,
+                           reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<unsigned short*>(out), nb, dim, max_period);
+    else
+        hipLaunchKernelGGL(timestep_embedding_kernel<0>, dim3((unsigned)((half + 63) / 64), (unsigned)nb), dim3(64), 0,
+                           reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<unsigned short*>(out), nb, dim, max_period);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }
@@ -255,11 +276,16 @@ extern "C" int sdmi_image_to_u8(const float* x, uint8_t* out, int32_t nb, int32_
 }
 
 extern "C" int sdmi_softmax_rows(const float* S, void* P, int64_t rows, int64_t cols, int64_t ld_s, int64_t ld_p,
-                                 void* stream) {
+                                 int32_t dtype, void* stream) {
+    SDMI_DT_CHECK(dtype);
     if (S == nullptr || P == nullptr || rows <= 0 || cols <= 0 || ld_s < cols || ld_p < cols) return SDMI_ERR_BAD_ARG;
     if (rows > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S,
-                       reinterpret_cast<unsigned short*>(P), cols, ld_s, ld_p);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S,
+                           reinterpret_cast<unsigned short*>(P), cols, ld_s, ld_p);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S,
+                           reinterpret_cast<unsigned short*>(P), cols, ld_s, ld_p);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }
@@ -270,7 +296,8 @@ extern "C" int64_t sdmi_softmax_cols_scratch_bytes(int32_t batch, int64_t cols) 
 }
 
 extern "C" int sdmi_softmax_cols(const float* ST, void* PT, float* colstats, int32_t batch, int64_t rows, int64_t cols,
-                                 void* stream) {
+                                 int32_t dtype, void* stream) {
+    SDMI_DT_CHECK(dtype);
     if (ST == nullptr || PT == nullptr || colstats == nullptr || batch <= 0 || rows <= 0 || cols <= 0)
         return SDMI_ERR_BAD_ARG;
     if (cols % 4 != 0) return SDMI_ERR_ALIGNMENT;
@@ -283,8 +310,12 @@ extern "C" int sdmi_softmax_cols(const float* ST, void* PT, float* colstats, int
     SDMI_CHECK_LAUNCH();
     hipLaunchKernelGGL(softmax_colmerge_kernel, dim3(cb, (unsigned)batch), dim3(256), 0, s, part, stats, cols, COL_SPLIT);
     SDMI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(softmax_colapply_kernel, dim3(grid_for(rows * (cols / 4), 256, 4096), (unsigned)batch), dim3(256),
-                       0, s, ST, reinterpret_cast<unsigned short*>(PT), stats, rows, cols);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(softmax_colapply_kernel<1>, dim3(grid_for(rows * (cols / 4), 256, 4096), (unsigned)batch), dim3(256),
+                           0, s, ST, reinterpret_cast<unsigned short*>(PT), stats, rows, cols);
+    else
+        hipLaunchKernelGGL(softmax_colapply_kernel<0>, dim3(grid_for(rows * (cols / 4), 256, 4096), (unsigned)batch), dim3(256),
+                           0, s, ST, reinterpret_cast<unsigned short*>(PT), stats, rows, cols);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

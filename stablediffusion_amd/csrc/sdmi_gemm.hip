@@ -55,6 +55,7 @@ __device__ __forceinline__ uint4 mask4(uint4 v, unsigned ok) {
 
 // Epilogue for 4 consecutive output columns of one row.  `v` is the raw accumulator quad (already
 // scaled and biased by the caller for the column-bias / GEGLU cases).
+template <int DT>
 __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, int64_t n, f32x4 v,
                                            int64_t zoff_out, int64_t zoff_res) {
     if (p.act == 1) {
@@ -80,21 +81,23 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
         const unsigned short* r = reinterpret_cast<const unsigned short*>(p.res) + zoff_res + m * p.ld_res + n;
         if (full) {
             const uint2 rv = *reinterpret_cast<const uint2*>(r);
-            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+            float rf[4];
+            elem_unpack4<DT>(rv, rf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rf[j];
         } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += bf16_bits_to_f32(r[j]);
+            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += elem_to_f32<DT>(r[j]);
         }
     }
     if (p.out_kind == 0) {
         unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n;
         if (full) {
             uint2 ov;
-            ov.x = pack_bf16x2(v[0], v[1]);
-            ov.y = pack_bf16x2(v[2], v[3]);
+            ov.x = elem_pack2<DT>(v[0], v[1]);
+            ov.y = elem_pack2<DT>(v[2], v[3]);
             *reinterpret_cast<uint2*>(o) = ov;
         } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = f32_to_bf16_bits(v[j]);
+            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = elem_from_f32<DT>(v[j]);
         }
     } else if (p.out_kind == 1) {
         float* o = reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n;
@@ -110,7 +113,7 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
     }
 }
 
-template <int MODE>
+template <int MODE, int DT>
 __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* const As = reinterpret_cast<uint4*>(smem);
@@ -265,17 +268,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pc = (ks * 4 + fq) ^ (frow & 7);
-            bf16x8 af[4], wf[4];
+            uint4 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = __builtin_bit_cast(bf16x8, Ab[a_base + i * 128 + pc]);
-                wf[i] = __builtin_bit_cast(bf16x8, Wb[w_base + i * 128 + pc]);
+                af[i] = Ab[a_base + i * 128 + pc];
+                wf[i] = Wb[w_base + i * 128 + pc];
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = mfma16<DT>(wf[ni], af[mi], acc[ni][mi]);
         }
         if (more) SDMI_STORE_TILE(cur ^ 1);
         __syncthreads();
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
-                store_quad(p, m, n, v, zoff_out, zoff_res);
+                store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
             }
         } else {
 #pragma unroll
@@ -333,13 +336,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
                         for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
                     }
                 }
-                store_quad(p, m, n, v, zoff_out, zoff_res);
+                store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
             }
         }
     }
 }
 
 // Second pass of split-K: sum the slabs and run the same epilogue.  One thread per output quad.
+template <int DT>
 __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_args p, int64_t ldw) {
     const int64_t n_w = p.geglu ? 2 * p.N : p.N;
     const int64_t quads_per_row = (n_w + 3) / 4;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
             for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
         }
         if (n >= p.N) continue;
-        store_quad(p, m, n, v, 0, 0);
+        store_quad<DT>(p, m, n, v, 0, 0);
     }
 }
 
@@ -389,6 +393,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (a->K % BK != 0) return SDMI_ERR_ALIGNMENT;
     if (a->mode != 0 && a->mode != 1) return SDMI_ERR_BAD_ARG;
     if (a->out_kind < 0 || a->out_kind > 2) return SDMI_ERR_BAD_ARG;
+    if (a->dtype != SDMI_DTYPE_BF16 && a->dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
     const int batch = a->batch > 0 ? a->batch : 1;
     const int split = a->split_k > 0 ? a->split_k : 1;
     if (batch > 1 && split > 1) return SDMI_ERR_BAD_ARG;
@@ -430,23 +435,28 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
-    if (p.mode == 0)
-        hipLaunchKernelGGL(sdmi_gemm_kernel<0>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
-    else
-        hipLaunchKernelGGL(sdmi_gemm_kernel<1>, grid, dim3(NTHREADS), LDS_BYTES, s, p);
+    const bool f16 = p.dtype == SDMI_DTYPE_F16;
+    if (p.mode == 0) {
+        if (f16) hipLaunchKernelGGL((sdmi_gemm_kernel<0, 1>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
+        else     hipLaunchKernelGGL((sdmi_gemm_kernel<0, 0>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
+    } else {
+        if (f16) hipLaunchKernelGGL((sdmi_gemm_kernel<1, 1>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
+        else     hipLaunchKernelGGL((sdmi_gemm_kernel<1, 0>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
+    }
     SDMI_CHECK_LAUNCH();
     if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);
         const int64_t blocks = (quads + 255) / 256;
-        hipLaunchKernelGGL(sdmi_gemm_splitk_reduce, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, p,
-                           tiles_n * BN);
+        const dim3 rgrid((unsigned)(blocks < 4096 ? blocks : 4096));
+        if (f16) hipLaunchKernelGGL(sdmi_gemm_splitk_reduce<1>, rgrid, dim3(256), 0, s, p, tiles_n * BN);
+        else     hipLaunchKernelGGL(sdmi_gemm_splitk_reduce<0>, rgrid, dim3(256), 0, s, p, tiles_n * BN);
         SDMI_CHECK_LAUNCH();
     }
     return SDMI_OK;

@@ -30,6 +30,7 @@ __device__ __forceinline__ uint4 gn_load(const unsigned short* x1, const unsigne
     return *reinterpret_cast<const uint4*>(x2 + pixel * C2 + (c - C1));
 }
 
+template <int DT>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned short* __restrict__ x1,
                                                               const unsigned short* __restrict__ x2, int C1, int C2,
                                                               int64_t hw, int64_t P, float* __restrict__ partial) {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
             for (int64_t pix = p_begin + trow; pix < p_end; pix += rows) {
                 const uint4 raw = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix, v);
                 float f[8];
-                unpack_bf16x8(raw, f);
+                elem_unpack8<DT>(raw, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
             }
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     stats[((int64_t)b * GN_GROUPS + g) * 2 + 1] = rsqrtf(var + eps);
 }
 
+template <int DT>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned short* __restrict__ x1,
                                                               const unsigned short* __restrict__ x2, int C1, int C2,
                                                               const float* __restrict__ gamma,
@@ -133,13 +135,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
             const int64_t gp = (int64_t)b * hw + pix;
             const uint4 raw = gn_load(x1, x2, C1, C2, gp, v);
             float f[8];
-            unpack_bf16x8(raw, f);
+            elem_unpack8<DT>(raw, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float y = f[j] * sc[j] + sf[j];
                 f[j] = silu ? silu_f(y) : y;
             }
-            *reinterpret_cast<uint4*>(out + gp * C + v * 8) = pack_bf16x8(f);
+            *reinterpret_cast<uint4*>(out + gp * C + v * 8) = elem_pack8<DT>(f);
         }
     }
 }
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
 // LayerNorm: one wave per row, row held in registers (C <= 2048), exact two-pass statistics.
 constexpr int LN_MAXV = 4;   // 64 lanes x 4 vectors x 8 = 2048 channels
 
+template <int DT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
             const int v = lane + 64 * i;
             if (v < nvec) {
                 const uint4 raw = *reinterpret_cast<const uint4*>(xr + v * 8);
-                unpack_bf16x8(raw, f[i]);
+                elem_unpack8<DT>(raw, f[i]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += f[i][j];
             }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
                     y[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
                     y[4 + j] = (f[i][4 + j] - mean) * rstd * g1[j] + b1[j];
                 }
-                *reinterpret_cast<uint4*>(orow + v * 8) = pack_bf16x8(y);
+                *reinterpret_cast<uint4*>(orow + v * 8) = elem_pack8<DT>(y);
             }
         }
     }
@@ -215,7 +218,8 @@ extern "C" int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw) {
 
 extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma,
                               const float* beta, void* out, int32_t nb, int64_t hw, float eps, int32_t silu,
-                              void* workspace, int64_t workspace_bytes, void* stream) {
+                              int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
     if (x1 == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (nb <= 0 || hw <= 0 || C1 <= 0 || C2 < 0) return SDMI_ERR_BAD_ARG;
     if ((x2 == nullptr) != (C2 == 0)) return SDMI_ERR_BAD_ARG;
@@ -232,28 +236,40 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const int nvec_h = C / 8;
     const int rows_h = GN_THREADS / (nvec_h < GN_THREADS ? nvec_h : GN_THREADS);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), lds * rows_h, s, reinterpret_cast<const unsigned short*>(x1),
-                       reinterpret_cast<const unsigned short*>(x2), C1, C2, hw, P, partial);
+    const unsigned short* u1 = reinterpret_cast<const unsigned short*>(x1);
+    const unsigned short* u2 = reinterpret_cast<const unsigned short*>(x2);
+    unsigned short* uo = reinterpret_cast<unsigned short*>(out);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<0>, grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial);
     SDMI_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(64), 0, s, partial, nslab, eps, stats);
     SDMI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), lds, s, reinterpret_cast<const unsigned short*>(x1),
-                       reinterpret_cast<const unsigned short*>(x2), C1, C2, gamma, beta, stats,
-                       reinterpret_cast<unsigned short*>(out), hw, P, silu);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, stats, uo, hw, P, silu);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, stats, uo, hw, P, silu);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }
 
 extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows,
-                              int32_t C, float eps, void* stream) {
+                              int32_t C, float eps, int32_t dtype, void* stream) {
+    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
     if (x == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (rows <= 0 || C <= 0) return SDMI_ERR_BAD_ARG;
     if (C % 8 != 0 || C > 64 * LN_MAXV * 8) return SDMI_ERR_ALIGNMENT;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
-                       rows, C, eps);
+    if (dtype == SDMI_DTYPE_F16)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
+                           rows, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
+                           rows, C, eps);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

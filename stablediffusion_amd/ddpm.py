@@ -118,6 +118,10 @@ class LatentDiffusion(nn.Module):
         self.first_stage_model = model.eval()
         for p in self.first_stage_model.parameters():
             p.requires_grad = False
+        # one precision policy for the whole path: the VAE follows the UNet's operand type
+        cd = getattr(self.model.diffusion_model, "compute_dtype", None)
+        if cd in (torch.bfloat16, torch.float16) and hasattr(model, "set_compute_dtype"):
+            model.set_compute_dtype(cd)
 
     def instantiate_cond_stage(self, config):
         if config is None or config == "__is_unconditional__":

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsdmi_hip.so")
 
 SDMI_OK = 0
+DTYPE_BF16, DTYPE_F16 = 0, 1
 
 
 class SdmiError(RuntimeError):
@@ -31,7 +32,7 @@ class GemmArgs(C.Structure):
         ("H", C.c_int32), ("W_in", C.c_int32), ("Cin", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("stride", C.c_int32), ("upsample", C.c_int32),
         ("out_kind", C.c_int32), ("geglu", C.c_int32), ("act", C.c_int32), ("bias_per_row", C.c_int32),
-        ("batch", C.c_int32), ("split_k", C.c_int32),
+        ("batch", C.c_int32), ("split_k", C.c_int32), ("dtype", C.c_int32),
         ("alpha", C.c_float),
     ]
 
@@ -44,16 +45,16 @@ SIGNATURES = {
     "sdmi_abi_version": (C.c_int, []),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
-    "sdmi_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp]),
+    "sdmi_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _vp, _i64, _vp]),
     "sdmi_groupnorm_workspace_bytes": (_i64, [_i32, _i64]),
-    "sdmi_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
-    "sdmi_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
-    "sdmi_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "sdmi_softmax_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _vp]),
+    "sdmi_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "sdmi_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _i32, _vp]),
+    "sdmi_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "sdmi_softmax_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp]),
     "sdmi_softmax_cols_scratch_bytes": (_i64, [_i32, _i64]),
-    "sdmi_nchw_f32_to_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _vp]),
-    "sdmi_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
-    "sdmi_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
+    "sdmi_nchw_f32_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _f32, _i32, _vp]),
+    "sdmi_cast_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "sdmi_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "sdmi_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "sdmi_image_to_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
 }

@@ -1,7 +1,8 @@
 """Tensor-level wrappers over the C ABI (include/sdmi.h): torch supplies device memory and the
 stream, the arithmetic happens in libsdmi_hip.so.  No op here has a PyTorch fallback.
 
-Activation convention: bf16, channels-last.  An image batch is a contiguous [B, H, W, C] tensor,
+Activation convention: 16-bit (bf16 or fp16 - the operand type of the MFMA kernels, chosen by the model's dtype
+policy), channels-last.  An image batch is a contiguous [B, H, W, C] tensor,
 which *is* the token matrix [B*H*W, C] the transformer blocks use (no permutes anywhere).
 """
 import ctypes as C
@@ -12,6 +13,8 @@ import torch
 from . import hip
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+HALF_TYPES = (BF16, F16)
 _BN = 128   # weight-row padding (GEMM N tile)
 _BK = 64    # K padding (GEMM K tile)
 
@@ -22,6 +25,14 @@ def _stream():
 
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dt(dtype):
+    if dtype == BF16:
+        return hip.DTYPE_BF16
+    if dtype == F16:
+        return hip.DTYPE_F16
+    raise hip.SdmiError(f"the HIP kernels take bf16 or fp16 operands, not {dtype}")
 
 
 def _require(t, dtype, name):
@@ -46,7 +57,8 @@ class PackedWeight:
     """bf16 [Npad, Kpad] weight (K contiguous) + fp32 bias in the layout sdmi_gemm expects."""
 
     def __init__(self, w, bias, n_out, k, geglu=False, cin=None):
-        self.w = w              # bf16 [Npad, Kpad]
+        self.w = w              # bf16|fp16 [Npad, Kpad]
+        self.dtype = w.dtype
         self.bias = bias        # fp32 [n_w] or None
         self.n_out = n_out      # output columns (after gating)
         self.k = k              # padded K
@@ -54,32 +66,32 @@ class PackedWeight:
         self.cin = cin          # conv3x3: (padded) input channels
 
 
-def _pad_pack(w2d):
+def _pad_pack(w2d, dtype=BF16):
     n, k = w2d.shape
-    out = torch.zeros(_round_up(n, _BN), _round_up(k, _BK), dtype=BF16, device=w2d.device)
-    out[:n, :k] = w2d.to(BF16)
+    out = torch.zeros(_round_up(n, _BN), _round_up(k, _BK), dtype=dtype, device=w2d.device)
+    out[:n, :k] = w2d.to(dtype)
     return out
 
 
-def pack_linear(weight, bias=None):
+def pack_linear(weight, bias=None, dtype=BF16):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
     w = weight.detach().reshape(weight.shape[0], -1).float()
     b = bias.detach().float().contiguous() if bias is not None else None
-    packed = _pad_pack(w)
+    packed = _pad_pack(w, dtype)
     return PackedWeight(packed, b, w.shape[0], packed.shape[1])
 
 
-def pack_linear_cat(weights, biases=None):
+def pack_linear_cat(weights, biases=None, dtype=BF16):
     """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections)."""
     w = torch.cat([x.detach().reshape(x.shape[0], -1).float() for x in weights], dim=0)
     b = None
     if biases is not None:
         b = torch.cat([x.detach().float() for x in biases]).contiguous()
-    packed = _pad_pack(w)
+    packed = _pad_pack(w, dtype)
     return PackedWeight(packed, b, w.shape[0], packed.shape[1])
 
 
-def pack_geglu(weight, bias):
+def pack_geglu(weight, bias, dtype=BF16):
     """GEGLU projection [2*inner, K]: rows [0,inner) = value, [inner,2*inner) = gate (attention.py:89).
     Packed row r holds value (half 0) or gate (half 1) column blk*16+i with blk=r//32, half=(r%32)//16, i=r%16."""
     w = weight.detach().float()
@@ -87,19 +99,19 @@ def pack_geglu(weight, bias):
     assert inner % 16 == 0
     r = torch.arange(2 * inner, device=w.device)
     src = ((r % 32) // 16) * inner + (r // 32) * 16 + (r % 16)
-    packed = _pad_pack(w[src])
+    packed = _pad_pack(w[src], dtype)
     b = bias.detach().float()[src].contiguous() if bias is not None else None
     return PackedWeight(packed, b, inner, packed.shape[1], geglu=True)
 
 
-def pack_conv3x3(weight, bias=None):
+def pack_conv3x3(weight, bias=None, dtype=BF16):
     """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8."""
     w = weight.detach().float()
     cout, cin = w.shape[0], w.shape[1]
     cin_p = _round_up(cin, 8)
     wp = torch.zeros(cout, 3, 3, cin_p, dtype=torch.float32, device=w.device)
     wp[..., :cin] = w.permute(0, 2, 3, 1)
-    packed = _pad_pack(wp.reshape(cout, 9 * cin_p))
+    packed = _pad_pack(wp.reshape(cout, 9 * cin_p), dtype)
     b = bias.detach().float().contiguous() if bias is not None else None
     return PackedWeight(packed, b, cout, packed.shape[1], cin=cin_p)
 
@@ -139,6 +151,7 @@ def _run_gemm(a, what):
 
 def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m):
     a.W = pw.w.data_ptr()
+    a.dtype = _dt(pw.dtype)
     a.bias = pw.bias.data_ptr() if (bias_on and pw.bias is not None) else None
     a.N = pw.n_out
     a.K = pw.k
@@ -160,7 +173,7 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.emb = emb.data_ptr()
         a.ld_emb = emb.stride(0)
     if res is not None:
-        _require(res, BF16, "res")
+        _require(res, pw.dtype, "res")
         a.res = res.data_ptr()
         a.ld_res = res.shape[-1]
     n_w = pw.n_out * (2 if pw.geglu else 1)
@@ -176,9 +189,11 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     return None
 
 
-def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=BF16, alpha=1.0, bias=True):
-    """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat)."""
-    _require(x, BF16, "x")
+def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True):
+    """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat).
+    out_dtype: None = the operand type, or torch.float32."""
+    _require(x, pw.dtype, "x")
+    out_dtype = out_dtype or pw.dtype
     k1 = x.shape[-1]
     m = x.numel() // k1
     a = hip.GemmArgs()
@@ -187,7 +202,7 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     a.lda = k1
     a.M = m
     if x2 is not None:
-        _require(x2, BF16, "x2")
+        _require(x2, pw.dtype, "x2")
         a.A2 = x2.data_ptr()
         a.lda2 = x2.shape[-1]
         a.k_split = k1
@@ -198,7 +213,7 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
             raise hip.SdmiError(f"linear: K mismatch ({k1} vs packed {pw.k})")
         a.k_valid = k1          # K padding of the packed weight: columns past k1 read as zero
     out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
-    keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype == BF16 else 1, alpha, m)
+    keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
     _run_gemm(a, "sdmi_gemm(linear)")
     del keep
     return out
@@ -206,8 +221,8 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
 
 def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False):
     """3x3 conv, pad 1, on an NHWC bf16 image [B, H, W, Cin]; optional fused nearest-x2 input gather,
-    time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC bf16, or fp32 NCHW."""
-    _require(x, BF16, "x")
+    time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC 16-bit, or fp32 NCHW."""
+    _require(x, pw.dtype, "x")
     b, h, w, cin = x.shape
     if cin != pw.cin:
         raise hip.SdmiError(f"conv3x3: Cin mismatch ({cin} vs packed {pw.cin})")
@@ -224,7 +239,7 @@ def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=Fa
     if out_nchw_f32:
         out = torch.empty(b, pw.n_out, ho, wo, dtype=torch.float32, device=x.device)
     else:
-        out = torch.empty(b, ho, wo, pw.n_out, dtype=BF16, device=x.device)
+        out = torch.empty(b, ho, wo, pw.n_out, dtype=pw.dtype, device=x.device)
     keep = _fill_common(a, pw, out, True, emb, ho * wo, res, 0, 2 if out_nchw_f32 else 0, 1.0, m)
     _run_gemm(a, "sdmi_gemm(conv3x3)")
     del keep
@@ -234,8 +249,10 @@ def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=Fa
 def gemm_nt_batched(a_mat, b_mat, out_dtype, alpha=1.0, bias_rows=None):
     """Batched out[z] = alpha * a[z] @ b[z]^T (+ bias per ROW).  a: [Z, M, K], b: [Z, N, K] bf16 (Z may be
     1-broadcast for a).  Used for the VAE single-head attention products."""
-    _require(a_mat, BF16, "a")
-    _require(b_mat, BF16, "b")
+    if a_mat.dtype not in HALF_TYPES:
+        raise hip.SdmiError("gemm_nt_batched: operands must be bf16 or fp16")
+    _require(a_mat, a_mat.dtype, "a")
+    _require(b_mat, a_mat.dtype, "b")
     z = b_mat.shape[0]
     m, k = a_mat.shape[-2], a_mat.shape[-1]
     n = b_mat.shape[-2]
@@ -247,7 +264,8 @@ def gemm_nt_batched(a_mat, b_mat, out_dtype, alpha=1.0, bias_rows=None):
     g.A, g.lda, g.M = a_mat.data_ptr(), k, m
     g.W, g.N, g.K = b_mat.data_ptr(), n, k
     g.out, g.ld_out = out.data_ptr(), n
-    g.out_kind = 0 if out_dtype == BF16 else 1
+    g.out_kind = 0 if out_dtype in HALF_TYPES else 1
+    g.dtype = _dt(a_mat.dtype)
     g.alpha = alpha
     g.batch = z
     g.split_k = 1
@@ -266,28 +284,30 @@ def gemm_nt_batched(a_mat, b_mat, out_dtype, alpha=1.0, bias_rows=None):
 
 
 def groupnorm(x1, gamma, beta, eps, silu, x2=None):
-    """GroupNorm(32)(+SiLU) over NHWC bf16; x2 = second half of a channel concat (read in place)."""
-    _require(x1, BF16, "x1")
-    _require(x2, BF16, "x2")
+    """GroupNorm(32)(+SiLU) over NHWC 16-bit; x2 = second half of a channel concat (read in place)."""
+    dt = _dt(x1.dtype)
+    _require(x1, x1.dtype, "x1")
+    _require(x2, x1.dtype, "x2")
     _require(gamma, torch.float32, "gamma")
     _require(beta, torch.float32, "beta")
     b = x1.shape[0]
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
     hw = x1.numel() // (b * c1)
-    out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=BF16, device=x1.device)
+    out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=x1.dtype, device=x1.device)
     nbytes = hip.lib().sdmi_groupnorm_workspace_bytes(b, hw)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x1.device)
     hip.check(hip.lib().sdmi_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b, hw, eps,
-                                       1 if silu else 0, _p(ws), nbytes, _stream()), "sdmi_groupnorm")
+                                       1 if silu else 0, dt, _p(ws), nbytes, _stream()), "sdmi_groupnorm")
     return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
-    _require(x, BF16, "x")
+    dt = _dt(x.dtype)
+    _require(x, x.dtype, "x")
     c = x.shape[-1]
     out = torch.empty_like(x)
-    hip.check(hip.lib().sdmi_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, _stream()),
+    hip.check(hip.lib().sdmi_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, dt, _stream()),
               "sdmi_layernorm")
     return out
 
@@ -298,60 +318,67 @@ def layernorm(x, gamma, beta, eps=1e-5):
 def attention_d64(q, k, v, heads, nb, nq, nk, scale):
     """q: [nb*nq, >=heads*64] (may be a column slice of a fused qkv buffer), k/v: [nb*nk, ...].
     Row strides are taken from the tensors; the innermost stride must be 1."""
+    dt = _dt(q.dtype)
     for t, name in ((q, "q"), (k, "k"), (v, "v")):
-        if t.dtype != BF16 or not t.is_cuda or t.stride(-1) != 1:
+        if t.dtype != q.dtype or not t.is_cuda or t.stride(-1) != 1:
             raise hip.SdmiError(f"attention: bad {name}")
-    out = torch.empty(nb * nq, heads * 64, dtype=BF16, device=q.device)
+    out = torch.empty(nb * nq, heads * 64, dtype=q.dtype, device=q.device)
     hip.check(hip.lib().sdmi_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
-                                           v.stride(0), out.stride(0), scale, _stream()), "sdmi_attention_d64")
+                                           v.stride(0), out.stride(0), scale, dt, _stream()), "sdmi_attention_d64")
     return out
 
 
-def softmax_rows(s):
-    """fp32 [R, Ccols] -> bf16 row softmax."""
+def softmax_rows(s, out_dtype=BF16):
+    """fp32 [R, Ccols] -> 16-bit row softmax."""
     _require(s, torch.float32, "s")
     rows, cols = s.numel() // s.shape[-1], s.shape[-1]
-    out = torch.empty(s.shape, dtype=BF16, device=s.device)
-    hip.check(hip.lib().sdmi_softmax_rows(_p(s), _p(out), rows, cols, cols, cols, _stream()), "sdmi_softmax_rows")
+    out = torch.empty(s.shape, dtype=out_dtype, device=s.device)
+    hip.check(hip.lib().sdmi_softmax_rows(_p(s), _p(out), rows, cols, cols, cols, _dt(out_dtype), _stream()),
+              "sdmi_softmax_rows")
     return out
 
 
-def softmax_cols(st):
-    """fp32 [Z, R, Ccols] -> bf16, softmax over the ROW index of every column."""
+def softmax_cols(st, out_dtype=BF16):
+    """fp32 [Z, R, Ccols] -> 16-bit, softmax over the ROW index of every column."""
     _require(st, torch.float32, "st")
     z, rows, cols = st.shape
-    out = torch.empty(st.shape, dtype=BF16, device=st.device)
+    out = torch.empty(st.shape, dtype=out_dtype, device=st.device)
     nbytes = hip.lib().sdmi_softmax_cols_scratch_bytes(z, cols)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=st.device)
-    hip.check(hip.lib().sdmi_softmax_cols(_p(st), _p(out), _p(ws), z, rows, cols, _stream()), "sdmi_softmax_cols")
+    hip.check(hip.lib().sdmi_softmax_cols(_p(st), _p(out), _p(ws), z, rows, cols, _dt(out_dtype), _stream()),
+              "sdmi_softmax_cols")
     return out
 
 
 # ----------------------------------------------------------------------------- edges
 
 
-def nchw_to_nhwc(x, cpad=None, scale=1.0):
-    """fp32 [B, C, H, W] -> bf16 [B, H, W, Cpad]."""
+def nchw_to_nhwc(x, cpad=None, scale=1.0, dtype=BF16):
+    """fp32 [B, C, H, W] -> 16-bit [B, H, W, Cpad]."""
     _require(x, torch.float32, "x")
     b, c, h, w = x.shape
     cpad = cpad or _round_up(c, 8)
-    out = torch.empty(b, h, w, cpad, dtype=BF16, device=x.device)
-    hip.check(hip.lib().sdmi_nchw_f32_to_nhwc_bf16(_p(x), _p(out), b, c, cpad, h * w, scale, _stream()),
-              "sdmi_nchw_f32_to_nhwc_bf16")
+    out = torch.empty(b, h, w, cpad, dtype=dtype, device=x.device)
+    hip.check(hip.lib().sdmi_nchw_f32_to_nhwc(_p(x), _p(out), b, c, cpad, h * w, scale, _dt(dtype), _stream()),
+              "sdmi_nchw_f32_to_nhwc")
+    return out
+
+
+def cast_f32(x, dtype=BF16):
+    _require(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    hip.check(hip.lib().sdmi_cast_f32(_p(x), _p(out), x.numel(), _dt(dtype), _stream()), "sdmi_cast_f32")
     return out
 
 
 def to_bf16(x):
-    _require(x, torch.float32, "x")
-    out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    hip.check(hip.lib().sdmi_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "sdmi_f32_to_bf16")
-    return out
+    return cast_f32(x, BF16)
 
 
-def timestep_embedding(t, dim, max_period=10000.0):
+def timestep_embedding(t, dim, max_period=10000.0, dtype=BF16):
     _require(t, torch.int64, "t")
-    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
-    hip.check(hip.lib().sdmi_timestep_embedding(_p(t), _p(out), t.shape[0], dim, max_period, _stream()),
+    out = torch.empty(t.shape[0], dim, dtype=dtype, device=t.device)
+    hip.check(hip.lib().sdmi_timestep_embedding(_p(t), _p(out), t.shape[0], dim, max_period, _dt(dtype), _stream()),
               "sdmi_timestep_embedding")
     return out
 

@@ -195,7 +195,10 @@ class UNetModel(nn.Module):
         self.use_checkpoint = use_checkpoint      # read by callers (txt2img.py:373); a no-op for inference
         self.dtype = torch.float16 if use_fp16 else torch.float32
         self.dtype = torch.bfloat16 if use_bf16 else self.dtype
-        self.compute_dtype = torch.bfloat16       # what the HIP kernels store activations/weights in
+        # The reference's dtype policy (openai_model.py:602-603) selects the 16-bit MFMA operand / storage type of
+        # the HIP kernels (same MFMA rate for both).  The fp32 policy (neither flag) needs f32-MFMA kernels that are
+        # not built yet; it raises at the first forward rather than silently computing at lower precision.
+        self.compute_dtype = self.dtype
         self.num_heads, self.num_head_channels = num_heads, num_head_channels
 
         ted = model_channels * 4
@@ -281,47 +284,51 @@ class UNetModel(nn.Module):
         if dev.type != "cuda":
             raise ops.hip.SdmiError("HIP UNetModel.forward needs the model on a GPU (model.cuda()); "
                                     "there is no CPU fallback")
+        if self.compute_dtype not in ops.HALF_TYPES:
+            raise NotImplementedError("HIP UNetModel: fp32 compute (use_fp16=False, use_bf16=False) is not built; "
+                                      "set use_bf16=True (bf16 MFMA) or use_fp16=True (f16 MFMA)")
+        cd = self.compute_dtype
         pk = {}
         f32 = lambda t: t.detach().float().contiguous()
         te = self.time_embedding
-        pk["te0"] = ops.pack_linear(te[0].weight, te[0].bias)
-        pk["te2"] = ops.pack_linear(te[2].weight, te[2].bias)
+        pk["te0"] = ops.pack_linear(te[0].weight, te[0].bias, dtype=cd)
+        pk["te2"] = ops.pack_linear(te[2].weight, te[2].bias, dtype=cd)
         # all ResBlock embedding projections as one [sum Cout, 4*mc] GEMM
         rbs = list(self._res_blocks())
         pk["emb_all"] = ops.pack_linear_cat([r.embedding_layers[1].weight for r in rbs],
-                                            [r.embedding_layers[1].bias for r in rbs])
+                                            [r.embedding_layers[1].bias for r in rbs], dtype=cd)
         off = 0
         for r in rbs:
             e = {"emb_off": off}
             off += r.out_channels
             e["gn1"] = (f32(r.in_layers[0].weight), f32(r.in_layers[0].bias))
-            e["conv1"] = ops.pack_conv3x3(r.in_layers[2].weight, r.in_layers[2].bias)
+            e["conv1"] = ops.pack_conv3x3(r.in_layers[2].weight, r.in_layers[2].bias, dtype=cd)
             e["gn2"] = (f32(r.out_layers[0].weight), f32(r.out_layers[0].bias))
-            e["conv2"] = ops.pack_conv3x3(r.out_layers[3].weight, r.out_layers[3].bias)
+            e["conv2"] = ops.pack_conv3x3(r.out_layers[3].weight, r.out_layers[3].bias, dtype=cd)
             if isinstance(r.skip_connection, nn.Conv2d):
                 if r.skip_connection.kernel_size != (1, 1):
                     raise NotImplementedError("3x3 skip_connection (use_conv=True) is outside the SD2 path")
-                e["skip"] = ops.pack_linear(r.skip_connection.weight, r.skip_connection.bias)
+                e["skip"] = ops.pack_linear(r.skip_connection.weight, r.skip_connection.bias, dtype=cd)
             pk[id(r)] = e
         # cross-attention K/V of every transformer block, one GEMM on the context
         kv_w = []
         kv_off = 0
         for st in self._transformers():
             e = {"norm": (f32(st.norm.weight), f32(st.norm.bias)),
-                 "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias),
-                 "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias), "blocks": []}
+                 "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias, dtype=cd),
+                 "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias, dtype=cd), "blocks": []}
             for tb in st.transformer_blocks:
                 c = tb.attn1.to_q.weight.shape[0]
                 be = {
                     "ln1": (f32(tb.norm1.weight), f32(tb.norm1.bias)),
                     "ln2": (f32(tb.norm2.weight), f32(tb.norm2.bias)),
                     "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
-                    "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight]),
-                    "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias),
-                    "q2": ops.pack_linear(tb.attn2.to_q.weight),
-                    "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias),
-                    "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias),
-                    "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias),
+                    "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd),
+                    "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd),
+                    "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd),
+                    "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd),
+                    "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd),
+                    "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd),
                     "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
                 }
                 if tb.attn1.dim_head != 64:
@@ -330,17 +337,17 @@ class UNetModel(nn.Module):
                 kv_off += 2 * c
                 e["blocks"].append(be)
             pk[id(st)] = e
-        pk["kv_all"] = ops.pack_linear_cat(kv_w)
+        pk["kv_all"] = ops.pack_linear_cat(kv_w, dtype=cd)
         for blk in list(self.input_blocks) + list(self.output_blocks):
             for layer in blk:
                 if isinstance(layer, nn.Conv2d):
-                    pk[id(layer)] = ops.pack_conv3x3(layer.weight, layer.bias)
+                    pk[id(layer)] = ops.pack_conv3x3(layer.weight, layer.bias, dtype=cd)
                 elif isinstance(layer, DownSample):
-                    pk[id(layer)] = ops.pack_conv3x3(layer.operation.weight, layer.operation.bias)
+                    pk[id(layer)] = ops.pack_conv3x3(layer.operation.weight, layer.operation.bias, dtype=cd)
                 elif isinstance(layer, UpSample):
-                    pk[id(layer)] = ops.pack_conv3x3(layer.conv.weight, layer.conv.bias)
+                    pk[id(layer)] = ops.pack_conv3x3(layer.conv.weight, layer.conv.bias, dtype=cd)
         pk["out_gn"] = (f32(self.out[0].weight), f32(self.out[0].bias))
-        pk["out_conv"] = ops.pack_conv3x3(self.out[2].weight, self.out[2].bias)
+        pk["out_conv"] = ops.pack_conv3x3(self.out[2].weight, self.out[2].bias, dtype=cd)
         self._pack = pk
         return pk
 
@@ -350,7 +357,8 @@ class UNetModel(nn.Module):
         key = (context.data_ptr(), tuple(context.shape), context._version, context.dtype)
         if self._ctx_cache is not None and self._ctx_cache[0] == key:
             return self._ctx_cache[1]
-        ctx = context if context.dtype == BF16 else ops.to_bf16(context.float().contiguous())
+        cd = self.compute_dtype
+        ctx = context if context.dtype == cd else ops.cast_f32(context.float().contiguous(), cd)
         kv = ops.linear(ctx.reshape(-1, ctx.shape[-1]), pk["kv_all"])     # [B*Nk, sum 2C]
         self._ctx_cache = (key, kv, context)   # keep `context` alive so data_ptr stays unique
         return kv
@@ -423,14 +431,14 @@ class UNetModel(nn.Module):
         if t.dim() == 0:
             t = t.expand(bsz).contiguous()
         # time path: sinusoid -> Linear -> SiLU -> Linear -> (SiLU, shared by all ResBlocks) -> 22 projections
-        te = ops.timestep_embedding(t, self.model_channels)
+        te = ops.timestep_embedding(t, self.model_channels, dtype=self.compute_dtype)
         e1 = ops.linear(te, pk["te0"], act=1)
         e2 = ops.linear(e1, pk["te2"], act=1)
         emb_all = ops.linear(e2, pk["emb_all"], out_dtype=torch.float32)
         kv = self._context_kv(pk, context)
         nk = context.shape[1]
 
-        h = ops.nchw_to_nhwc(x.float().contiguous())
+        h = ops.nchw_to_nhwc(x.float().contiguous(), dtype=self.compute_dtype)
         hs = []
         for blk in self.input_blocks:
             h = self._run_block(pk, blk, h, None, emb_all, kv, nk)

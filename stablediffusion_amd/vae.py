@@ -70,8 +70,9 @@ class Decoder(nn.Module):
     def __init__(self, *, channels=None, out_channels=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions,
                  dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False,
                  tanh_out=False, use_linear_attn=False, attn_type="vanilla", ch=None, out_ch=None,
-                 vae_attn="reference", **ignorekwargs):
+                 vae_attn="reference", compute_dtype=torch.bfloat16, **ignorekwargs):
         super().__init__()
+        self.compute_dtype = compute_dtype
         channels = channels if channels is not None else ch
         out_channels = out_channels if out_channels is not None else out_ch
         if channels is None or out_channels is None:
@@ -118,6 +119,14 @@ class Decoder(nn.Module):
     def invalidate_packed(self):
         self._pack = None
 
+    def set_compute_dtype(self, dtype):
+        """bf16 or fp16 storage / MFMA operand type (LatentDiffusion aligns it with the UNet's policy)."""
+        if dtype not in ops.HALF_TYPES:
+            raise NotImplementedError("HIP Decoder: compute dtype must be torch.bfloat16 or torch.float16")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._pack = None
+
     @torch.no_grad()
     def _build_pack(self):
         dev = next(self.parameters()).device
@@ -125,27 +134,28 @@ class Decoder(nn.Module):
             raise ops.hip.SdmiError("HIP Decoder.forward needs the model on a GPU; there is no CPU fallback")
         f32 = lambda t: t.detach().float().contiguous()
         pk = {}
+        cd = self.compute_dtype
         for m in self.modules():
             if isinstance(m, ResnetBlock):
-                e = {"gn1": (f32(m.norm1.weight), f32(m.norm1.bias)), "conv1": ops.pack_conv3x3(m.conv1.weight, m.conv1.bias),
-                     "gn2": (f32(m.norm2.weight), f32(m.norm2.bias)), "conv2": ops.pack_conv3x3(m.conv2.weight, m.conv2.bias)}
+                e = {"gn1": (f32(m.norm1.weight), f32(m.norm1.bias)), "conv1": ops.pack_conv3x3(m.conv1.weight, m.conv1.bias, dtype=cd),
+                     "gn2": (f32(m.norm2.weight), f32(m.norm2.bias)), "conv2": ops.pack_conv3x3(m.conv2.weight, m.conv2.bias, dtype=cd)}
                 if hasattr(m, "nin_shortcut"):
-                    e["skip"] = ops.pack_linear(m.nin_shortcut.weight, m.nin_shortcut.bias)
+                    e["skip"] = ops.pack_linear(m.nin_shortcut.weight, m.nin_shortcut.bias, dtype=cd)
                 pk[id(m)] = e
             elif isinstance(m, AttnBlock):
                 c = m.in_channels
                 pk[id(m)] = {
                     "gn": (f32(m.norm.weight), f32(m.norm.bias)),
-                    "q": ops.pack_linear(m.q.weight, m.q.bias), "k": ops.pack_linear(m.k.weight, m.k.bias),
+                    "q": ops.pack_linear(m.q.weight, m.q.bias, dtype=cd), "k": ops.pack_linear(m.k.weight, m.k.bias, dtype=cd),
                     # V^T = Wv . Xn^T needs Wv as the (unpadded-row) A operand and its bias per row
-                    "wv": m.v.weight.detach().reshape(c, c).to(BF16).contiguous()[None], "bv": f32(m.v.bias),
-                    "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias),
+                    "wv": m.v.weight.detach().reshape(c, c).to(cd).contiguous()[None], "bv": f32(m.v.bias),
+                    "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias, dtype=cd),
                 }
             elif isinstance(m, UpSample):
-                pk[id(m)] = ops.pack_conv3x3(m.conv.weight, m.conv.bias)
-        pk["conv_in"] = ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias)
+                pk[id(m)] = ops.pack_conv3x3(m.conv.weight, m.conv.bias, dtype=cd)
+        pk["conv_in"] = ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, dtype=cd)
         pk["norm_out"] = (f32(self.norm_out.weight), f32(self.norm_out.bias))
-        pk["conv_out"] = ops.pack_conv3x3(self.conv_out.weight, self.conv_out.bias)
+        pk["conv_out"] = ops.pack_conv3x3(self.conv_out.weight, self.conv_out.bias, dtype=cd)
         self._pack = pk
         return pk
 
@@ -169,29 +179,30 @@ class Decoder(nn.Module):
         scale = float(int(c) ** (-0.5))
         hn_p = _pad_rows(hn, 128)
         npad = hn_p.shape[1]
-        vt = ops.gemm_nt_batched(e["wv"], hn_p, BF16, bias_rows=e["bv"])       # [b, c, npad]: V^T (+bias per channel)
+        cd = self.compute_dtype
+        vt = ops.gemm_nt_batched(e["wv"], hn_p, cd, bias_rows=e["bv"])       # [b, c, npad]: V^T (+bias per channel)
         if npad != n:
             vt[:, :, n:] = 0
         if self.vae_attn == "reference":
             # ST[j, i] = scale * k_j . q_i ; PT[j, i] = W[i, j] (softmax over j) ; O[j, :] = sum_i PT[j, i] V[i, :]
             st = ops.gemm_nt_batched(k, _pad_rows(q, 128), torch.float32, alpha=scale)[:, :, :n].contiguous() \
                 if npad != n else ops.gemm_nt_batched(k, q, torch.float32, alpha=scale)
-            pt = ops.softmax_cols(st)
+            pt = ops.softmax_cols(st, cd)
         elif self.vae_attn == "standard":
             st = ops.gemm_nt_batched(q, _pad_rows(k, 128), torch.float32, alpha=scale)[:, :, :n].contiguous() \
                 if npad != n else ops.gemm_nt_batched(q, k, torch.float32, alpha=scale)
-            pt = ops.softmax_rows(st)
+            pt = ops.softmax_rows(st, cd)
         else:
             raise ValueError(f"vae_attn must be 'reference' or 'standard', got {self.vae_attn!r}")
         if n % 64:
             raise NotImplementedError("VAE attention needs h*w % 64 == 0")
         if npad != n:   # K (= token count) of the last product must match between P and V^T
-            ptp = torch.zeros(b, n, npad, dtype=BF16, device=h.device)
+            ptp = torch.zeros(b, n, npad, dtype=cd, device=h.device)
             ptp[:, :, :n] = pt
             pt = ptp
         cp = (c + 127) // 128 * 128
         vt_p = _pad_rows(vt, 128) if cp != c else vt
-        o = ops.gemm_nt_batched(pt, vt_p, BF16)[:, :, :c]
+        o = ops.gemm_nt_batched(pt, vt_p, cd)[:, :, :c]
         if cp != c:
             o = o.contiguous()
         out = ops.linear(o.reshape(b * n, c), e["proj"], res=h.reshape(b * n, c))
@@ -202,7 +213,8 @@ class Decoder(nn.Module):
         """z: fp32 NCHW latent [B, z_channels, h, w] (or an already-NHWC bf16 tensor from decode()) ->
         fp32 NCHW image [B, out_channels, 8h, 8w] (model.py:371-411)."""
         pk = self._pack or self._build_pack()
-        h = z if z.dtype == BF16 else ops.nchw_to_nhwc(z.float().contiguous(), scale=scale)
+        h = z if z.dtype in ops.HALF_TYPES else ops.nchw_to_nhwc(z.float().contiguous(), scale=scale,
+                                                                  dtype=self.compute_dtype)
         h = ops.conv3x3(h, pk["conv_in"])
         h = self._resnet(pk, self.mid.block_1, h)
         h = self._attn(pk, self.mid.attn_1, h)
@@ -222,7 +234,7 @@ class Decoder(nn.Module):
 class AutoencoderKL(nn.Module):
     def __init__(self, dd_config=None, loss_config=None, embedding_dim=None, ckpt_path=None, ignore_keys=(),
                  image_key="image", colorize_nlabels=None, monitor=None, ema_decay=None, learn_log_var=False,
-                 ddconfig=None, lossconfig=None, embed_dim=None, vae_attn="reference"):
+                 ddconfig=None, lossconfig=None, embed_dim=None, vae_attn="reference", compute_dtype=torch.bfloat16):
         super().__init__()
         dd_config = dict(dd_config if dd_config is not None else ddconfig)
         loss_config = loss_config if loss_config is not None else lossconfig
@@ -233,7 +245,7 @@ class AutoencoderKL(nn.Module):
         self.embedding_dim = embedding_dim
         # The encoder half (img2img / training only) is outside the denoising hot path.
         self.encoder = None
-        self.decoder = Decoder(vae_attn=vae_attn, **dd_config)
+        self.decoder = Decoder(vae_attn=vae_attn, compute_dtype=compute_dtype, **dd_config)
         self.loss = instantiate_from_config(loss_config) if loss_config is not None else None
         self.post_quant_conv = nn.Conv2d(embedding_dim, dd_config["z_channels"], 1)
         if monitor is not None:
@@ -260,6 +272,10 @@ class AutoencoderKL(nn.Module):
         self._pq = None
         return super()._apply(fn, *a, **kw)
 
+    def set_compute_dtype(self, dtype):
+        self.decoder.set_compute_dtype(dtype)
+        self._pq = None
+
     def encode(self, x):
         raise NotImplementedError("AutoencoderKL.encode: the VAE encoder is outside the denoising hot path")
 
@@ -275,8 +291,9 @@ class AutoencoderKL(nn.Module):
             wp[:zc, :ed] = w.reshape(zc, ed)
             bp = torch.zeros(zp, device=w.device)
             bp[:zc] = self.post_quant_conv.bias.detach().float()
-            self._pq = ops.pack_linear(wp, bp)     # output channels padded to 8 (zeros) for conv_in's 16-byte loads
-        h = ops.nchw_to_nhwc(z.float().contiguous(), cpad=self._pq.k, scale=scale)   # [B, h, w, 64], zero padded
+            self._pq = ops.pack_linear(wp, bp, dtype=self.decoder.compute_dtype)     # output channels padded to 8 (zeros) for conv_in's 16-byte loads
+        h = ops.nchw_to_nhwc(z.float().contiguous(), cpad=self._pq.k, scale=scale,
+                             dtype=self.decoder.compute_dtype)                        # [B, h, w, 64], zero padded
         h = ops.linear(h, self._pq)                                                    # [B, h, w, 8]
         return self.decoder(h)
 

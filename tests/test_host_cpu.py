@@ -66,9 +66,10 @@ def test_argument_validation_without_gpu(lib):
     a.A, a.W, a.out = 16, 16, 16
     a.M, a.N, a.K = 8, 8, 100
     assert lib.sdmi_gemm(ctypes.byref(a), None) == -2          # K not a multiple of 64
-    assert lib.sdmi_layernorm(None, None, None, None, 1, 8, 1e-5, None) == -1
-    assert lib.sdmi_attention_d64(16, 16, 16, 16, 1, 1, 8, 8, 60, 64, 64, 64, 0.125, None) == -2
-    assert lib.sdmi_groupnorm(16, None, 30, 0, 16, 16, 16, 1, 8, 1e-5, 1, 16, 1 << 20, None) == -2
+    assert lib.sdmi_layernorm(None, None, None, None, 1, 8, 1e-5, 0, None) == -1
+    assert lib.sdmi_attention_d64(16, 16, 16, 16, 1, 1, 8, 8, 60, 64, 64, 64, 0.125, 0, None) == -2
+    assert lib.sdmi_attention_d64(16, 16, 16, 16, 1, 1, 8, 8, 64, 64, 64, 64, 0.125, 7, None) == -1     # unknown dtype
+    assert lib.sdmi_groupnorm(16, None, 30, 0, 16, 16, 16, 1, 8, 1e-5, 1, 0, 16, 1 << 20, None) == -2
 
 
 def test_factory_surface():

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 
 
 def _ops():
@@ -326,3 +327,35 @@ def test_kernels_are_deterministic(dev):
     qkv = rnd((1024, 3 * 320), dev, 6).to(BF16)
     f = lambda: ops.attention_d64(qkv[:, :320], qkv[:, 320:640], qkv[:, 640:], 5, 1, 1024, 1024, 0.125)
     assert torch.equal(f(), f())
+
+
+@pytest.mark.parametrize("dt", [F16])
+def test_fp16_operand_type(dev, dt):
+    """The same kernels instantiated for f16 operands (the reference's `use_fp16` policy): 8x finer mantissa."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    m, n, k = 300, 320, 1280
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    res = rnd((m, n), dev, 4)
+    out = ops.linear(x.to(dt), ops.pack_linear(w, b, dtype=dt), res=res.to(dt))
+    assert out.dtype == dt
+    assert rel_err(out, F.linear(qd(x), qd(w), b) + qd(res)) < 1e-3
+    with pytest.raises(Exception):
+        ops.linear(x.to(BF16), ops.pack_linear(w, b, dtype=dt))          # mixed operand types are rejected
+    xi = rnd((2, 64, 16, 16), dev, 5)
+    wt, bias = rnd((128, 64, 3, 3), dev, 6, 1 / 24), rnd((128,), dev, 7)
+    out = ops.conv3x3(qd(xi).permute(0, 2, 3, 1).contiguous().to(dt), ops.pack_conv3x3(wt, bias, dtype=dt))
+    assert rel_err(out.permute(0, 3, 1, 2), F.conv2d(qd(xi), qd(wt), bias, padding=1)) < 1e-3
+    g = rnd((2, 256, 320), dev, 8) * 2 + 0.7
+    gamma, beta = 1 + 0.2 * rnd((320,), dev, 9), 0.1 * rnd((320,), dev, 10)
+    out = ops.groupnorm(g.to(dt), gamma, beta, 1e-5, True)
+    assert rel_err(out.permute(0, 2, 1), F.silu(F.group_norm(qd(g).permute(0, 2, 1), 32, gamma, beta, 1e-5))) < 1e-3
+    out = ops.layernorm(g.reshape(512, 320).to(dt), gamma, beta)
+    assert rel_err(out, F.layer_norm(qd(g).reshape(512, 320), (320,), gamma, beta, 1e-5)) < 1e-3
+    nb, heads, nq, nk = 2, 5, 256, 77
+    c = heads * 64
+    qq, kk, vv = rnd((nb * nq, c), dev, 11), rnd((nb * nk, c), dev, 12), rnd((nb * nk, c), dev, 13)
+    out = ops.attention_d64(qq.to(dt), kk.to(dt), vv.to(dt), heads, nb, nq, nk, 0.125)
+    assert rel_err(out, _attn_ref(qd(qq), qd(kk), qd(vv), nb, heads, nq, nk, 0.125)) < 2e-3
+    assert torch.equal(ops.cast_f32(x, dt), x.to(dt))
+    assert ops.nchw_to_nhwc(rnd((1, 4, 8, 8), dev, 14), dtype=dt).dtype == dt
