@@ -147,8 +147,8 @@ int64_t sdmi_softmax_cols_scratch_bytes(int32_t batch, int64_t cols);
 /* fp32 NCHW [nb, C, hw] -> 16-bit (dtype) NHWC [nb, hw, Cpad] (channels >= C zero), value * scale.
  * Entry of UNetModel.forward (openai_model.py:980) and of decode_first_stage (z / scale_factor,
  * configs/stable-diffusion/v2-inference.yaml:17). */
-int sdmi_nchw_f32_to_nhwc_bf16(const float* x, void* out, int32_t nb, int32_t C, int32_t Cpad, int64_t hw,
-                               float scale, int32_t dtype, void* stream);
+int sdmi_nchw_f32_to_nhwc(const float* x, void* out, int32_t nb, int32_t C, int32_t Cpad, int64_t hw,
+                          float scale, int32_t dtype, void* stream);
 /* fp32 -> 16-bit (dtype) cast of a contiguous buffer (context embeddings, openai_model.py:940 `context`). */
 int sdmi_cast_f32(const float* x, void* out, int64_t n, int32_t dtype, void* stream);
 /* Sinusoidal timestep embedding, cos first then sin (ldm/utils.py:301-318, repaired B1/B2):
