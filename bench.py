@@ -111,19 +111,29 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T):
         fn()
         torch.cuda.synchronize()
         tr, ops.TRACE = ops.TRACE, None
-        return [(k, f, e0.elapsed_time(e1) * 1e-3, sk) for k, f, e0, e1, sk in tr]
+        return [(k, f, e0.elapsed_time(e1) * 1e-3, sk, shp) for k, f, e0, e1, sk, shp in tr]
 
     collect(lambda: model.apply_model(x_in, ts, c_in))       # warm
     un = collect(lambda: model.apply_model(x_in, ts, c_in))
     de = collect(lambda: model.decode_first_stage(x_T))
     out = {}
     for kind in ("conv3x3", "linear"):
-        u = [(f, t) for k, f, t, _ in un if k == kind]
-        d = [(f, t) for k, f, t, _ in de if k == kind]
+        u = [(f, t) for k, f, t, _, _ in un if k == kind]
+        d = [(f, t) for k, f, t, _, _ in de if k == kind]
         fl = ddim_steps * sum(f for f, _ in u) + sum(f for f, _ in d)
         tm = ddim_steps * sum(t for _, t in u) + sum(t for _, t in d)
         n = ddim_steps * len(u) + len(d)
         out[kind] = (fl, tm, n)
+    if os.environ.get("SDMI_DUMP_SHAPES"):      # per-shape table of one UNet forward + one decode (development aid)
+        agg = {}
+        for src, lst in (("unet", un), ("dec", de)):
+            for k, f, t, sk, shp in lst:
+                e = agg.setdefault((src, k) + shp + (sk,), [0, 0.0, 0.0])
+                e[0] += 1; e[1] += t; e[2] += f
+        with open(os.environ["SDMI_DUMP_SHAPES"], "w") as fh:
+            fh.write("src kind M N K stride ups splitk calls total_us TFLOPs\n")
+            for key, (n_, t_, f_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                fh.write(" ".join(str(x) for x in key) + f" {n_} {t_ * 1e6:.1f} {f_ / t_ / 1e12:.1f}\n")
     fl, tm, n = out["conv3x3"]
     lf, lt, ln = out["linear"]
     return {"bound": "mfma", "achieved": fl / tm / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -12,13 +12,18 @@
 // tile and the "B" operand is the activation tile, so an accumulator register quad holds 4
 // CONSECUTIVE output columns of one output row: epilogue loads/stores are 8-16 byte vectors.
 // LDS: double-buffered A and W tiles, 64 KiB, XOR-swizzled 16-byte chunks (conflict-free
-// ds_read_b128); global loads for tile k+1 are issued before the MFMAs of tile k and written
-// to LDS after them (register staging: the conv gather needs per-lane addresses and zero fill).
+// ds_read_b128), filled by global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip, no ds_write -
+// the ds_write_b128 path alone would cost ~0.8 of the MFMA time of a tile).  The gather of the
+// implicit GEMM is expressed in the per-lane SOURCE address (zero taps read a zero constant);
+// the DMA of tile k+1 is issued before the MFMAs of tile k and retired at the barrier.
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous, group-M-swizzled
 // range of tiles.
 #include "sdmi_common.h"
 
 namespace {
+
+// 16 bytes of zeros: the DMA source of padded rows / out-of-image taps
+__device__ const uint4 sdmi_zero16 = {0u, 0u, 0u, 0u};
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NTHREADS = 256;
@@ -44,13 +49,6 @@ __device__ __forceinline__ TileCoord tile_of_block(int bid, int tiles_m, int til
     t.tm = first_m + in_g % gsz;
     t.tn = in_g / gsz;
     return t;
-}
-
-// Loads of invalid rows / taps go to an always-valid address and are zeroed BY VALUE (a `c ? *p : zero`
-// expression makes clang select between ADDRESSES, one of them a scratch copy of the zero).
-__device__ __forceinline__ uint4 mask4(uint4 v, unsigned ok) {
-    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-    return v;
 }
 
 // Epilogue for 4 consecutive output columns of one row.  `v` is the raw accumulator quad (already
@@ -148,8 +146,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     const unsigned short* const W = reinterpret_cast<const unsigned short*>(p.W) + zoff_w;
 
     // ---- loader geometry: thread owns 16-byte chunk `lc` of rows lr + 32*i ----
-    const int lc = tid & 7;
-    const int lr = tid >> 3;
+    const int lr = tid >> 3;                    // tile rows lr + 32*i
+    const int lc = (tid & 7) ^ (lr & 7);        // LOGICAL 16-byte chunk fetched into physical chunk tid&7
 
     int64_t a_off[4];      // MODE 0: m * lda (and m*lda2 recomputed);  MODE 1: pixel base b*H*W
     int iy0[4], ix0[4];    // MODE 1
@@ -170,7 +168,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
             ix0[i] = ox * p.stride - 1;
         }
     }
-    const unsigned rowmask = (rvalid[0] ? 1u : 0u) | (rvalid[1] ? 2u : 0u) | (rvalid[2] ? 4u : 0u) | (rvalid[3] ? 8u : 0u);
     const int64_t k_valid = p.k_valid > 0 ? p.k_valid : p.K;
     const int Hl = p.H << p.upsample, Wl = p.W_in << p.upsample;
     // conv k-state for this thread's chunk: k = kt*64 + lc*8 -> (tap, ci)
@@ -184,62 +181,69 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     const unsigned short* w_ptr = W + (n0 + lr) * p.K + (int64_t)kt_begin * BK + lc * 8;
     const int64_t w_row32 = 32 * p.K;
 
-    // Register staging for the next k-tile.  Named scalars, not arrays: hipcc keeps a uint4[4] that is
-    // written in one branch and read in another in scratch memory.
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    // ---- staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction) ----
+    // A wave-instruction writes LDS at (wave-uniform base) + lane*16, i.e. 8 consecutive tile rows x 8 physical
+    // chunks.  The XOR swizzle therefore goes on the SOURCE address: lane l owns physical chunk l&7 of row
+    // 32*i + 8*wave + (l>>3) and fetches logical chunk (l&7) ^ (row&7) (set up above as `lc`).  Rows / taps that
+    // must read as zero fetch from a 16-byte zero constant instead (the DMA cannot mask).
+    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(&sdmi_zero16);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    // Issued through inline asm on purpose: with the builtin, hipcc orders every later ds_read of the tile
+    // being computed behind the DMA of the NEXT tile (s_waitcnt vmcnt(0) ahead of the MFMAs), which serialises
+    // load and compute.  The asm form is invisible to its wait-count pass; the DMA is retired by the explicit
+    // s_waitcnt vmcnt(0) in front of the barrier that ends the k-step.  M0 (LDS destination) is written and
+    // restored inside the statement (cdna_hip_programming.md §5.7).
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#define SDMI_GLDS(SRC, LDSBYTE)                                                                            \
+    do {                                                                                                   \
+        unsigned keep_;                                                                                    \
+        const void* src_ = (SRC);                                                                          \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (LDSBYTE));                        \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                              \
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                                 \
+                     : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                    \
+    } while (0)
+    // LDS byte offset of instruction i of this wave inside one operand tile: (256*i + 64*wave) chunks
+#define SDMI_TILE_OFF(I) (((256 * (I)) + 64 * wave_u) * 16)
 
-    // The zero fill of invalid rows/taps is applied when the registers are written to LDS (okmask), so the
-    // global loads stay in flight across the MFMAs of the current tile.
-    unsigned okmask = 0;
-#define SDMI_LOAD_A0(I, DST, KK, BASE, LD) \
-    DST = *reinterpret_cast<const uint4*>((BASE) + ((rvalid[I] && kin_) ? a_off[I] * (LD) + (KK) : 0))
-#define SDMI_LOAD_A1(I, DST, KY, KX, TV)                                                               \
-    do {                                                                                               \
-        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                  \
-        const bool ok_ = (TV) && (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;         \
-        iy_ >>= p.upsample; ix_ >>= p.upsample;                                                        \
-        const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin + c_ci;                  \
-        okmask |= (ok_ ? 1u : 0u) << (I);                                                              \
-        DST = *reinterpret_cast<const uint4*>(A + (ok_ ? off_ : 0));                                   \
+#define SDMI_STAGE_A0(I, KK, BASE, LD, BUFBYTE)                                                            \
+    SDMI_GLDS((rvalid[I] && kin_) ? (BASE) + a_off[I] * (LD) + (KK) : zsrc, (BUFBYTE) + SDMI_TILE_OFF(I))
+#define SDMI_STAGE_A1(I, KY, KX, TV, BUFBYTE)                                                              \
+    do {                                                                                                   \
+        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                      \
+        const bool ok_ = (TV) && (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;             \
+        iy_ >>= p.upsample; ix_ >>= p.upsample;                                                            \
+        const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin + c_ci;                      \
+        SDMI_GLDS(ok_ ? A + off_ : zsrc, (BUFBYTE) + SDMI_TILE_OFF(I));                                    \
     } while (0)
 
-#define SDMI_LOAD_TILE(KT)                                                                             \
-    do {                                                                                               \
-        if (MODE == 0) {                                                                               \
-            const int64_t k_ = (int64_t)(KT) * BK + lc * 8;                                            \
-            const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */   \
-            const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                 \
-            const unsigned short* base_ = second_ ? A2 : A;                                            \
-            const int64_t ld_ = second_ ? p.lda2 : p.lda;                                              \
-            const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                         \
-            SDMI_LOAD_A0(0, ra0, kk_, base_, ld_); SDMI_LOAD_A0(1, ra1, kk_, base_, ld_);              \
-            SDMI_LOAD_A0(2, ra2, kk_, base_, ld_); SDMI_LOAD_A0(3, ra3, kk_, base_, ld_);              \
-            okmask = kin_ ? rowmask : 0u;                                                              \
-        } else {                                                                                       \
-            const int ky_ = c_tap / 3, kx_ = c_tap - 3 * ky_;                                          \
-            const bool tapvalid_ = c_tap < 9;                                                          \
-            okmask = 0;                                                                                \
-            SDMI_LOAD_A1(0, ra0, ky_, kx_, tapvalid_); SDMI_LOAD_A1(1, ra1, ky_, kx_, tapvalid_);      \
-            SDMI_LOAD_A1(2, ra2, ky_, kx_, tapvalid_); SDMI_LOAD_A1(3, ra3, ky_, kx_, tapvalid_);      \
-            c_ci += BK;                                                                                \
-            while (c_ci >= p.Cin) { c_ci -= p.Cin; ++c_tap; }                                          \
-        }                                                                                              \
-        rw0 = *reinterpret_cast<const uint4*>(w_ptr);                                                  \
-        rw1 = *reinterpret_cast<const uint4*>(w_ptr + w_row32);                                        \
-        rw2 = *reinterpret_cast<const uint4*>(w_ptr + 2 * w_row32);                                    \
-        rw3 = *reinterpret_cast<const uint4*>(w_ptr + 3 * w_row32);                                    \
-        w_ptr += BK;                                                                                   \
-    } while (0)
-
-    // LDS chunk index of row lr + 32*i: (lr + 32 i) * 8 + (lc ^ (lr & 7))
-    const int st_idx = lr * 8 + (lc ^ (lr & 7));
-#define SDMI_STORE_TILE(BUF)                                                                           \
-    do {                                                                                               \
-        uint4* a_ = As + (BUF) * TILE_CHUNKS + st_idx;                                                 \
-        uint4* w_ = Ws + (BUF) * TILE_CHUNKS + st_idx;                                                 \
-        a_[0] = mask4(ra0, okmask & 1u); a_[256] = mask4(ra1, okmask & 2u);                            \
-        a_[512] = mask4(ra2, okmask & 4u); a_[768] = mask4(ra3, okmask & 8u);                          \
-        w_[0] = rw0; w_[256] = rw1; w_[512] = rw2; w_[768] = rw3;                                      \
+    // Issue the DMA of k-tile KT into buffer BUF (A tile at BUF*16 KiB, W tile at 32 KiB + BUF*16 KiB).
+#define SDMI_STAGE_TILE(KT, BUF)                                                                           \
+    do {                                                                                                   \
+        const int abyte_ = (BUF) * (TILE_CHUNKS * 16);                                                     \
+        const int wbyte_ = (2 + (BUF)) * (TILE_CHUNKS * 16);                                               \
+        if (MODE == 0) {                                                                                   \
+            const int64_t k_ = (int64_t)(KT) * BK + lc * 8;                                                \
+            const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */       \
+            const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                     \
+            const unsigned short* base_ = second_ ? A2 : A;                                                \
+            const int64_t ld_ = second_ ? p.lda2 : p.lda;                                                  \
+            const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                             \
+            SDMI_STAGE_A0(0, kk_, base_, ld_, abyte_); SDMI_STAGE_A0(1, kk_, base_, ld_, abyte_);          \
+            SDMI_STAGE_A0(2, kk_, base_, ld_, abyte_); SDMI_STAGE_A0(3, kk_, base_, ld_, abyte_);          \
+        } else {                                                                                           \
+            const int ky_ = c_tap / 3, kx_ = c_tap - 3 * ky_;                                              \
+            const bool tapvalid_ = c_tap < 9;                                                              \
+            SDMI_STAGE_A1(0, ky_, kx_, tapvalid_, abyte_); SDMI_STAGE_A1(1, ky_, kx_, tapvalid_, abyte_);  \
+            SDMI_STAGE_A1(2, ky_, kx_, tapvalid_, abyte_); SDMI_STAGE_A1(3, ky_, kx_, tapvalid_, abyte_);  \
+            c_ci += BK;                                                                                    \
+            while (c_ci >= p.Cin) { c_ci -= p.Cin; ++c_tap; }                                              \
+        }                                                                                                  \
+        SDMI_GLDS(w_ptr, wbyte_ + SDMI_TILE_OFF(0));                                                       \
+        SDMI_GLDS(w_ptr + w_row32, wbyte_ + SDMI_TILE_OFF(1));                                             \
+        SDMI_GLDS(w_ptr + 2 * w_row32, wbyte_ + SDMI_TILE_OFF(2));                                         \
+        SDMI_GLDS(w_ptr + 3 * w_row32, wbyte_ + SDMI_TILE_OFF(3));                                         \
+        w_ptr += BK;                                                                                       \
     } while (0)
 
     f32x4 acc[4][4];   // [ni][mi]
@@ -253,16 +257,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     const int a_base = (wm * 64 + frow) * 8;
     const int w_base = (wn * 64 + frow) * 8;
 
-    if (kt_begin < kt_end) {
-        SDMI_LOAD_TILE(kt_begin);
-        SDMI_STORE_TILE(0);
-    }
+    if (kt_begin < kt_end) SDMI_STAGE_TILE(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         const bool more = kt + 1 < kt_end;
-        if (more) SDMI_LOAD_TILE(kt + 1);
+        if (more) SDMI_STAGE_TILE(kt + 1, cur ^ 1);     // DMA of the next tile flies under this tile's MFMAs
         const uint4* Ab = As + cur * TILE_CHUNKS;
         const uint4* Wb = Ws + cur * TILE_CHUNKS;
 #pragma unroll
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = mfma16<DT>(wf[ni], af[mi], acc[ni][mi]);
         }
-        if (more) SDMI_STORE_TILE(cur ^ 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of tile kt+1 has landed
+        __syncthreads();                                     // ... and everyone's; buffer `cur` is free again
     }
 
     // ---- epilogue ----

@@ -146,7 +146,8 @@ def _run_gemm(a, what):
     e0.record()
     hip.check(hip.lib().sdmi_gemm(C.byref(a), _stream()), what)
     e1.record()
-    TRACE.append(("conv3x3" if a.mode == 1 else "linear", _gemm_flops(a), e0, e1, int(a.split_k)))
+    TRACE.append(("conv3x3" if a.mode == 1 else "linear", _gemm_flops(a), e0, e1, int(a.split_k),
+                  (int(a.M), int(a.N) * (2 if a.geglu else 1), int(a.K), int(a.stride), int(a.upsample))))
 
 
 def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m):

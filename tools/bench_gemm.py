@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of sdmi_gemm on the shapes of the SD2 path (development aid).
+usage: python tools/bench_gemm.py [iters]   -> one line per shape: us, TFLOP/s"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stablediffusion_amd import ops
+
+dev = torch.device("cuda:0")
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+only = sys.argv[2] if len(sys.argv) > 2 else None
+BF16 = torch.bfloat16
+SHAPES = [  # kind, args
+    ("conv", (16, 64, 64, 320, 320)), ("conv", (16, 32, 32, 640, 640)), ("conv", (16, 16, 16, 1280, 1280)),
+    ("conv", (16, 8, 8, 1280, 1280)), ("conv", (16, 64, 64, 640, 320)), ("conv", (8, 256, 256, 256, 256)),
+    ("conv", (8, 128, 128, 512, 512)), ("conv", (8, 512, 512, 128, 128)),
+    ("lin", (65536, 320, 320)), ("lin", (65536, 2560, 320)), ("lin", (65536, 320, 1280)), ("lin", (16384, 640, 640)),
+    ("lin", (16384, 5120, 640)), ("lin", (4096, 1280, 1280)), ("lin", (4096, 10240, 1280)), ("lin", (8192, 8192, 8192)),
+]
+for kind, a in SHAPES:
+    if only and only != kind:
+        continue
+    if kind == "conv":
+        b, h, w, cin, cout = a
+        x = torch.randn(b, h, w, cin, device=dev).to(BF16)
+        pw = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, torch.randn(cout, device=dev))
+        fn = lambda: ops.conv3x3(x, pw)
+        flops = 2 * b * h * w * cout * 9 * cin
+    else:
+        m, n, k = a
+        x = torch.randn(m, k, device=dev).to(BF16)
+        pw = ops.pack_linear(torch.randn(n, k, device=dev) * 0.02, torch.randn(n, device=dev))
+        res = torch.randn(m, n, device=dev).to(BF16)
+        fn = lambda: ops.linear(x, pw, res=res)
+        flops = 2 * m * n * k
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    print(f"{kind:5s} {str(a):32s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
