@@ -51,8 +51,9 @@ int sdmi_abi_version(void);
  * openai_model.py:106-114 / model.py:137-141 (fused gather); torch.cat([h, skip]) feeding a 1x1
  * conv at openai_model.py:1010 (two-pointer A).
  *
- * W is PRE-PACKED by the caller: bf16 [Npad][K], K contiguous, Npad = N_w rounded up to 128,
- * rows >= N_w zero.  K must be a multiple of 64 (pad with zero columns).
+ * W is PRE-PACKED by the caller: 16-bit [Npad][K], K contiguous, Npad = N_w rounded up to tile_n
+ * (128, or 160 for widths that are multiples of 160 -- no GEGLU), rows >= N_w zero.  K must be a
+ * multiple of 64 (pad with zero columns).
  *   mode 0 (linear / 1x1 conv): A is [M, lda] row-major; if A2 != NULL columns [0,k_split) come
  *       from A and [k_split,K) from A2 (row stride lda2); k_split % 64 == 0.  If the logical width of A
  *       is not a multiple of 64, pass it as k_valid: columns [k_valid, K) read as zero.
@@ -90,6 +91,7 @@ typedef struct sdmi_gemm_args {
     int32_t batch, split_k;
     int32_t dtype;                      /* sdmi_dtype of A, A2, W, res and of out when out_kind == 0 */
     float alpha;
+    int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it */
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);

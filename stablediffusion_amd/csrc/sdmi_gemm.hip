@@ -25,10 +25,12 @@ namespace {
 // 16 bytes of zeros: the DMA source of padded rows / out-of-image taps
 __device__ const uint4 sdmi_zero16 = {0u, 0u, 0u, 0u};
 
-constexpr int BM = 128, BN = 128, BK = 64;
+// Block tile BM x BN x BK with BN = 32*TN: TN = 4 (128 columns) or TN = 5 (160 columns; every UNet width is a
+// multiple of 160, so those layers lose nothing to column padding).
+constexpr int BM = 128, BK = 64;
 constexpr int NTHREADS = 256;
-constexpr int TILE_CHUNKS = BM * (BK / 8);          // 16-byte chunks per operand tile (1024)
-constexpr int LDS_BYTES = 4 * TILE_CHUNKS * 16;     // A0 A1 W0 W1 = 64 KiB
+constexpr int TILE_CHUNKS = BM * (BK / 8);          // 16-byte chunks per A tile (1024)
+constexpr int lds_bytes(int tn) { return 2 * TILE_CHUNKS * 16 + 2 * (tn * 32) * (BK / 8) * 16; }   // A0 A1 W0 W1
 constexpr int GROUP_M = 8;
 
 struct TileCoord { int tm, tn; };
@@ -111,8 +113,10 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
     }
 }
 
-template <int MODE, int DT>
+template <int MODE, int DT, int TN>
 __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
+    constexpr int BN = TN * 32;                 // 2 waves across N, TN 16-column blocks each
+    constexpr int W_CHUNKS = BN * (BK / 8);     // 16-byte chunks per W tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* const As = reinterpret_cast<uint4*>(smem);
     uint4* const Ws = reinterpret_cast<uint4*>(smem) + 2 * TILE_CHUNKS;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
 #define SDMI_STAGE_TILE(KT, BUF)                                                                           \
     do {                                                                                                   \
         const int abyte_ = (BUF) * (TILE_CHUNKS * 16);                                                     \
-        const int wbyte_ = (2 + (BUF)) * (TILE_CHUNKS * 16);                                               \
+        const int wbyte_ = 2 * (TILE_CHUNKS * 16) + (BUF) * (W_CHUNKS * 16);                               \
         if (MODE == 0) {                                                                                   \
             const int64_t k_ = (int64_t)(KT) * BK + lc * 8;                                                \
             const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */       \
@@ -243,19 +247,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
         SDMI_GLDS(w_ptr + w_row32, wbyte_ + SDMI_TILE_OFF(1));                                             \
         SDMI_GLDS(w_ptr + 2 * w_row32, wbyte_ + SDMI_TILE_OFF(2));                                         \
         SDMI_GLDS(w_ptr + 3 * w_row32, wbyte_ + SDMI_TILE_OFF(3));                                         \
+        if (TN == 5) SDMI_GLDS(w_ptr + 4 * w_row32, wbyte_ + SDMI_TILE_OFF(4));                            \
         w_ptr += BK;                                                                                       \
     } while (0)
 
-    f32x4 acc[4][4];   // [ni][mi]
+    f32x4 acc[TN][4];   // [ni][mi]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15;
     const int fq = lane >> 4;
     const int a_base = (wm * 64 + frow) * 8;
-    const int w_base = (wn * 64 + frow) * 8;
+    const int w_base = (wn * (TN * 16) + frow) * 8;
 
     if (kt_begin < kt_end) SDMI_STAGE_TILE(kt_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -266,18 +271,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
         const bool more = kt + 1 < kt_end;
         if (more) SDMI_STAGE_TILE(kt + 1, cur ^ 1);     // DMA of the next tile flies under this tile's MFMAs
         const uint4* Ab = As + cur * TILE_CHUNKS;
-        const uint4* Wb = Ws + cur * TILE_CHUNKS;
+        const uint4* Wb = Ws + cur * W_CHUNKS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pc = (ks * 4 + fq) ^ (frow & 7);
-            uint4 af[4], wf[4];
+            uint4 af[4], wf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = Ab[a_base + i * 128 + pc];
-                wf[i] = Wb[w_base + i * 128 + pc];
-            }
+            for (int i = 0; i < 4; ++i) af[i] = Ab[a_base + i * 128 + pc];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int i = 0; i < TN; ++i) wf[i] = Wb[w_base + i * 128 + pc];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = mfma16<DT>(wf[ni], af[mi], acc[ni][mi]);
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
 
     // ---- epilogue ----
     // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*64 + mi*16 + (lane&15),
-    // weight row (column of out) wcol = n0 + wn*64 + ni*16 + 4*(lane>>4) + j.
+    // weight row (column of out) wcol = n0 + wn*16*TN + ni*16 + 4*(lane>>4) + j.
     if (p.split_k > 1) {
         // raw partial sums to the workspace slab of this slice: [split][M][tiles_n*BN] fp32
         float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)z * p.M * ((int64_t)tiles_n * BN);
@@ -298,8 +302,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
             const int64_t m = m0 + wm * 64 + mi * 16 + frow;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int64_t wcol = n0 + wn * 64 + ni * 16 + 4 * fq;
+            for (int ni = 0; ni < TN; ++ni) {
+                const int64_t wcol = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
                 *reinterpret_cast<f32x4*>(ws + m * ldw + wcol) = acc[ni][mi];
             }
         }
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
         if (m >= p.M) continue;
         if (p.geglu) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ni += 2) {
-                const int64_t wcol = n0 + wn * 64 + ni * 16 + 4 * fq;
+            for (int ni = 0; ni + 1 < TN; ni += 2) {     // GEGLU runs with TN == 4 only (host-checked)
+                const int64_t wcol = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
                 const int64_t n = (wcol >> 5) * 16 + (wcol & 15);
                 if (n >= p.N) continue;
                 f32x4 v = acc[ni][mi] * p.alpha, g = acc[ni + 1][mi] * p.alpha;
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
             }
         } else {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int64_t n = n0 + wn * 64 + ni * 16 + 4 * fq;
+            for (int ni = 0; ni < TN; ++ni) {
+                const int64_t n = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
                 if (n >= p.N) continue;
                 f32x4 v = acc[ni][mi] * p.alpha;
                 if (p.bias != nullptr && !p.bias_per_row) {
@@ -383,9 +387,12 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
 
 }  // namespace
 
+static int64_t slab_ld(int64_t N_w, int tile_n) { return (N_w + tile_n - 1) / tile_n * tile_n; }
+
 extern "C" int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k) {
     if (split_k <= 1) return 0;
-    const int64_t ldw = (N_w + BN - 1) / BN * BN;
+    // enough for either column tile (128 or 160)
+    const int64_t ldw = slab_ld(N_w, 128) > slab_ld(N_w, 160) ? slab_ld(N_w, 128) : slab_ld(N_w, 160);
     return (int64_t)split_k * M * ldw * (int64_t)sizeof(float);
 }
 
@@ -427,31 +434,34 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     p.batch = batch;
     p.split_k = split;
     const int64_t n_w = p.geglu ? 2 * p.N : p.N;
+    const int BN = p.tile_n == 0 ? 128 : p.tile_n;
+    if (BN != 128 && BN != 160) return SDMI_ERR_BAD_ARG;
+    if (BN == 160 && p.geglu) return SDMI_ERR_BAD_ARG;      // GEGLU pairs 16-column blocks inside a wave
     const int64_t tiles_m = (p.M + BM - 1) / BM, tiles_n = (n_w + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
     if (split > 1) {
         if (split > p.K / BK) return SDMI_ERR_BAD_ARG;
-        if (p.workspace == nullptr || p.workspace_bytes < sdmi_gemm_workspace_bytes(p.M, n_w, split))
+        if (p.workspace == nullptr || p.workspace_bytes < (int64_t)split * p.M * slab_ld(n_w, BN) * (int64_t)sizeof(float))
             return SDMI_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    typedef void (*kern_t)(const sdmi_gemm_args);
+    static const kern_t kernels[2][2][2] = {     // [mode][dtype][tile_n == 160]
+        {{sdmi_gemm_kernel<0, 0, 4>, sdmi_gemm_kernel<0, 0, 5>}, {sdmi_gemm_kernel<0, 1, 4>, sdmi_gemm_kernel<0, 1, 5>}},
+        {{sdmi_gemm_kernel<1, 0, 4>, sdmi_gemm_kernel<1, 0, 5>}, {sdmi_gemm_kernel<1, 1, 4>, sdmi_gemm_kernel<1, 1, 5>}}};
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdmi_gemm_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int c = 0; c < 2; ++c)
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b][c]),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(c ? 5 : 4));
         attr_done = true;
     }
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
-    if (p.mode == 0) {
-        if (f16) hipLaunchKernelGGL((sdmi_gemm_kernel<0, 1>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
-        else     hipLaunchKernelGGL((sdmi_gemm_kernel<0, 0>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
-    } else {
-        if (f16) hipLaunchKernelGGL((sdmi_gemm_kernel<1, 1>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
-        else     hipLaunchKernelGGL((sdmi_gemm_kernel<1, 0>), grid, dim3(NTHREADS), LDS_BYTES, s, p);
-    }
+    const int wide = BN == 160;
+    hipLaunchKernelGGL(kernels[p.mode][f16 ? 1 : 0][wide], grid, dim3(NTHREADS), lds_bytes(wide ? 5 : 4), s, p);
     SDMI_CHECK_LAUNCH();
     if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);

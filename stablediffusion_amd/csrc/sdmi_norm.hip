@@ -3,11 +3,12 @@
 // Both are HBM-bound: every global access is a 16-byte (8 x bf16) vector, fully coalesced because an
 // NHWC tensor [nb, hw, C] is one contiguous [nb*hw, C] matrix.  Statistics are fp32.
 //
-// GroupNorm runs as three launches on the caller's stream:
-//   1. gn_stats:    grid (slabs, nb) - each block reduces a slab of pixels to per-group (n, mean, M2)
-//   2. gn_finalize: grid (nb)        - Chan/Welford merge of the slab partials -> (mean, rstd) per group
-//   3. gn_apply:    grid (slabs, nb) - y = silu(x * scale[c] + shift[c]) with scale/shift tables in LDS
-// The second read of x in pass 3 is served from L2 / Infinity Cache for the UNet's tensor sizes.
+// GroupNorm runs as two launches on the caller's stream:
+//   1. gn_stats: grid (slabs, nb) - each block reduces a slab of pixels to per-group (n, mean, M2)
+//   2. gn_apply: grid (slabs, nb) - Chan/Welford merge of the image's slab partials -> (mean, rstd) per group
+//                                   (redone by every block, in a fixed order), then
+//                                   y = silu(x * scale[c] + shift[c]) with scale/shift tables in LDS
+// The second read of x in pass 2 is served from L2 / Infinity Cache for the UNet's tensor sizes.
 // The input may be the channel concatenation of two tensors (two base pointers).
 #include "sdmi_common.h"
 
@@ -82,23 +83,14 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
     }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nslab, float eps,
-                                                         float* __restrict__ stats) {
-    const int b = blockIdx.x, g = threadIdx.x;
-    if (g >= GN_GROUPS) return;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < nslab; ++s) {
-        const float* pp = partial + (((int64_t)b * nslab + s) * GN_GROUPS + g) * 3;
-        const float nb = pp[0], mb = pp[1], m2b = pp[2];
-        const float tot = n + nb;
-        const float delta = mb - mean;
-        mean += delta * (nb / tot);
-        m2 += m2b + delta * delta * (n * nb / tot);
-        n = tot;
-    }
-    const float var = m2 / n;
-    stats[((int64_t)b * GN_GROUPS + g) * 2 + 0] = mean;
-    stats[((int64_t)b * GN_GROUPS + g) * 2 + 1] = rsqrtf(var + eps);
+// Chan/Welford merge of two (n, mean, M2) summaries; an empty right-hand side leaves the left unchanged.
+__device__ __forceinline__ void gn_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb == 0.f) return;
+    const float tot = n + nb;
+    const float delta = mb - mean;
+    mean += delta * (nb / tot);
+    m2 += m2b + delta * delta * (n * nb / tot);
+    n = tot;
 }
 
 template <int DT>
@@ -106,16 +98,38 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ x2, int C1, int C2,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
-                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ partial, float eps,
                                                               unsigned short* __restrict__ out, int64_t hw, int64_t P,
                                                               int silu) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // scale[C], shift[C]
+    __shared__ float sub_stat[GN_THREADS / GN_GROUPS][GN_GROUPS][3];
+    __shared__ float grp_stat[GN_GROUPS][2];
     const int C = C1 + C2, nvec = C >> 3, cpg = C / GN_GROUPS;
-    const int b = blockIdx.y, slab = blockIdx.x;
+    const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
     const int tid = threadIdx.x;
+    // Every block merges the slab partials of its image itself (fixed order: 8 interleaved chains per group,
+    // then the 8 chain results in order), which replaces a separate single-block finalize launch.
+    {
+        const int g = tid & (GN_GROUPS - 1), sub = tid / GN_GROUPS;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int sl = sub; sl < nslab; sl += GN_THREADS / GN_GROUPS) {
+            const float* pp = partial + (((int64_t)b * nslab + sl) * GN_GROUPS + g) * 3;
+            gn_merge(n, mean, m2, pp[0], pp[1], pp[2]);
+        }
+        sub_stat[sub][g][0] = n; sub_stat[sub][g][1] = mean; sub_stat[sub][g][2] = m2;
+    }
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int sub = 0; sub < GN_THREADS / GN_GROUPS; ++sub)
+            gn_merge(n, mean, m2, sub_stat[sub][tid][0], sub_stat[sub][tid][1], sub_stat[sub][tid][2]);
+        grp_stat[tid][0] = mean;
+        grp_stat[tid][1] = rsqrtf(m2 / n + eps);
+    }
+    __syncthreads();
     for (int c = tid; c < C; c += GN_THREADS) {
         const int g = c / cpg;
-        const float mean = stats[((int64_t)b * GN_GROUPS + g) * 2], rstd = stats[((int64_t)b * GN_GROUPS + g) * 2 + 1];
+        const float mean = grp_stat[g][0], rstd = grp_stat[g][1];
         const float sc = rstd * gamma[c];
         sh[c] = sc;
         sh[C + c] = beta[c] - mean * sc;
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
 extern "C" int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw) {
     const int64_t P = gn_slab_pixels(hw);
     const int64_t nslab = (hw + P - 1) / P;
-    return ((int64_t)nb * nslab * GN_GROUPS * 3 + (int64_t)nb * GN_GROUPS * 2) * (int64_t)sizeof(float);
+    return (int64_t)nb * nslab * GN_GROUPS * 3 * (int64_t)sizeof(float);
 }
 
 extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma,
@@ -230,7 +244,6 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     const int64_t P = gn_slab_pixels(hw);
     const int nslab = (int)((hw + P - 1) / P);
     float* partial = reinterpret_cast<float*>(workspace);
-    float* stats = partial + (int64_t)nb * nslab * GN_GROUPS * 3;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)nslab, (unsigned)nb);
     const size_t lds = 2 * (size_t)C * sizeof(float);
@@ -244,12 +257,10 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     else
         hipLaunchKernelGGL(gn_stats_kernel<0>, grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial);
     SDMI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(64), 0, s, partial, nslab, eps, stats);
-    SDMI_CHECK_LAUNCH();
     if (dtype == SDMI_DTYPE_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, stats, uo, hw, P, silu);
+        hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, stats, uo, hw, P, silu);
+        hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

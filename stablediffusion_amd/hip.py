@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("out_kind", C.c_int32), ("geglu", C.c_int32), ("act", C.c_int32), ("bias_per_row", C.c_int32),
         ("batch", C.c_int32), ("split_k", C.c_int32), ("dtype", C.c_int32),
         ("alpha", C.c_float),
+        ("tile_n", C.c_int32),
     ]
 
 

@@ -6,6 +6,7 @@ policy), channels-last.  An image batch is a contiguous [B, H, W, C] tensor,
 which *is* the token matrix [B*H*W, C] the transformer blocks use (no permutes anywhere).
 """
 import ctypes as C
+import functools
 import math
 
 import torch
@@ -15,7 +16,7 @@ from . import hip
 BF16 = torch.bfloat16
 F16 = torch.float16
 HALF_TYPES = (BF16, F16)
-_BN = 128   # weight-row padding (GEMM N tile)
+_BN = 128   # default GEMM column tile (weight-row padding); 160 for widths that are multiples of 160
 _BK = 64    # K padding (GEMM K tile)
 
 
@@ -56,8 +57,9 @@ def _round_up(x, m):
 class PackedWeight:
     """bf16 [Npad, Kpad] weight (K contiguous) + fp32 bias in the layout sdmi_gemm expects."""
 
-    def __init__(self, w, bias, n_out, k, geglu=False, cin=None):
+    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN):
         self.w = w              # bf16|fp16 [Npad, Kpad]
+        self.tile_n = tile_n    # column tile the rows are padded for (128 | 160)
         self.dtype = w.dtype
         self.bias = bias        # fp32 [n_w] or None
         self.n_out = n_out      # output columns (after gating)
@@ -66,29 +68,37 @@ class PackedWeight:
         self.cin = cin          # conv3x3: (padded) input channels
 
 
-def _pad_pack(w2d, dtype=BF16):
+def _tile_n_for(n, geglu=False):
+    """160-column tiles where they divide the width (all SD UNet widths: 320, 640, 960, 1280, 1920, ...):
+    no padded columns and more MFMA work per barrier.  GEGLU pairs 16-column blocks, which needs 128."""
+    return 160 if (n % 160 == 0 and not geglu) else _BN
+
+
+def _pad_pack(w2d, dtype=BF16, tile_n=_BN):
     n, k = w2d.shape
-    out = torch.zeros(_round_up(n, _BN), _round_up(k, _BK), dtype=dtype, device=w2d.device)
+    out = torch.zeros(_round_up(n, tile_n), _round_up(k, _BK), dtype=dtype, device=w2d.device)
     out[:n, :k] = w2d.to(dtype)
     return out
 
 
-def pack_linear(weight, bias=None, dtype=BF16):
+def pack_linear(weight, bias=None, dtype=BF16, tile_n=None):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
     w = weight.detach().reshape(weight.shape[0], -1).float()
     b = bias.detach().float().contiguous() if bias is not None else None
-    packed = _pad_pack(w, dtype)
-    return PackedWeight(packed, b, w.shape[0], packed.shape[1])
+    tn = tile_n or _tile_n_for(w.shape[0])
+    packed = _pad_pack(w, dtype, tn)
+    return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn)
 
 
-def pack_linear_cat(weights, biases=None, dtype=BF16):
+def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None):
     """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections)."""
     w = torch.cat([x.detach().reshape(x.shape[0], -1).float() for x in weights], dim=0)
     b = None
     if biases is not None:
         b = torch.cat([x.detach().float() for x in biases]).contiguous()
-    packed = _pad_pack(w, dtype)
-    return PackedWeight(packed, b, w.shape[0], packed.shape[1])
+    tn = tile_n or _tile_n_for(w.shape[0])
+    packed = _pad_pack(w, dtype, tn)
+    return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn)
 
 
 def pack_geglu(weight, bias, dtype=BF16):
@@ -104,27 +114,47 @@ def pack_geglu(weight, bias, dtype=BF16):
     return PackedWeight(packed, b, inner, packed.shape[1], geglu=True)
 
 
-def pack_conv3x3(weight, bias=None, dtype=BF16):
+def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
     """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8."""
     w = weight.detach().float()
     cout, cin = w.shape[0], w.shape[1]
     cin_p = _round_up(cin, 8)
     wp = torch.zeros(cout, 3, 3, cin_p, dtype=torch.float32, device=w.device)
     wp[..., :cin] = w.permute(0, 2, 3, 1)
-    packed = _pad_pack(wp.reshape(cout, 9 * cin_p), dtype)
+    tn = tile_n or _tile_n_for(cout)
+    packed = _pad_pack(wp.reshape(cout, 9 * cin_p), dtype, tn)
     b = bias.detach().float().contiguous() if bias is not None else None
-    return PackedWeight(packed, b, cout, packed.shape[1], cin=cin_p)
+    return PackedWeight(packed, b, cout, packed.shape[1], cin=cin_p, tile_n=tn)
 
 
 # ----------------------------------------------------------------------------- GEMM family
 
 
-def _auto_split_k(m, n_w, k):
-    tiles = math.ceil(m / 128) * math.ceil(n_w / 128)
+_CUS = 256            # MI355X compute units; two GEMM blocks are co-resident on each
+_PAIR_SLOWDOWN = 1.35  # two co-resident blocks take this long relative to one alone (measured ~1.3-1.4)
+
+
+@functools.lru_cache(maxsize=None)
+def _auto_split_k(m, n_w, k, tile_n=_BN):
+    """Split-K factor from a small occupancy model, in units of one block k-tile step.  A launch of B blocks
+    puts ceil(B/256) blocks on the busiest CU, which runs them two at a time; each block costs nk/s steps plus
+    a fixed prologue/epilogue; splitting adds the fp32 slab write + the reduce pass.  Constants fitted to
+    tools/bench_gemm.py SWEEP=1 on MI355X (round 1: predicted vs measured within ~5% on the UNet conv shapes)."""
+    tiles = math.ceil(m / 128) * math.ceil(n_w / tile_n)
     nk = k // _BK
-    if tiles >= 200 or nk < 8:
-        return 1
-    return max(1, min(512 // tiles, nk // 4, 16))
+    step_us = 128 * tile_n * _BK * 2 / (2.5e9 / _CUS * 0.29)      # one k-tile step of a lone block, microseconds
+    best, best_cost = 1, None
+    for s in range(1, 17):
+        if s > 1 and nk // s < 2:
+            break
+        per_cu = math.ceil(tiles * s / _CUS)
+        work = math.ceil(nk / s) + 4
+        cost = (per_cu // 2) * _PAIR_SLOWDOWN * work + (per_cu % 2) * work
+        if s > 1:
+            cost += ((2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 3.0) / step_us   # slab write+read (mostly L2/MALL) + launch
+        if best_cost is None or cost < best_cost * 0.97:
+            best, best_cost = s, cost
+    return best
 
 
 # Optional per-launch instrumentation (bench.py's roofline leg): when TRACE is a list, every sdmi_gemm
@@ -178,7 +208,8 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.res = res.data_ptr()
         a.ld_res = res.shape[-1]
     n_w = pw.n_out * (2 if pw.geglu else 1)
-    sk = _auto_split_k(m, n_w, pw.k)
+    a.tile_n = pw.tile_n
+    sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)
     if sk > 1:
         nbytes = hip.lib().sdmi_gemm_workspace_bytes(m, n_w, sk)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)

@@ -209,7 +209,7 @@ def test_weight_packing_layouts():
         assert torch.equal(pg.w[r, :64], wg[half * 64 + col].to(torch.bfloat16)) and float(pg.bias[r]) == float(bg[half * 64 + col])
     pc = ops.pack_linear_cat([torch.ones(3, 64), 2 * torch.ones(5, 64)])
     assert pc.n_out == 8 and float(pc.w[2, 0]) == 1 and float(pc.w[3, 0]) == 2
-    assert ops._auto_split_k(65536, 320, 2880) == 1 and ops._auto_split_k(128, 1280, 23040) == 16
+    assert ops._auto_split_k(65536, 320, 2880) == 1 and ops._auto_split_k(128, 1280, 23040) >= 8
 
 
 def test_dp_shard_ranges():

@@ -118,6 +118,29 @@ def test_split_k(dev):
     assert rel_err(out, a * F.gelu(gate)) < 1e-4
 
 
+@pytest.mark.parametrize("n", [160, 320, 200, 960])
+def test_column_tile_variants_agree(dev, n, monkeypatch):
+    """The 128- and 160-column tiles accumulate every output in the same k order: bit-identical results
+    for linear and conv (split-K pinned to 1: the heuristic may split the two tilings differently)."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: 1)
+    m, k = 300, 1280
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    outs = [ops.linear(x.to(BF16), ops.pack_linear(w, b, tile_n=t), out_dtype=torch.float32) for t in (128, 160)]
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[1], F.linear(q(x), q(w), b)) < 1e-4
+    xi = rnd((2, 8, 8, 64), dev, 4).to(BF16)
+    wt, bias = rnd((n, 64, 3, 3), dev, 5, 1 / 24), rnd((n,), dev, 6)
+    outs = [ops.conv3x3(xi, ops.pack_conv3x3(wt, bias, tile_n=t)) for t in (128, 160)]
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(xi.float().permute(0, 3, 1, 2), q(wt), bias, padding=1)
+    assert rel_err(outs[1].permute(0, 3, 1, 2), ref) < 6e-3
+    with pytest.raises(Exception):
+        pw = ops.pack_geglu(rnd((640, 64), dev, 7), rnd((640,), dev, 8))
+        pw.tile_n = 160
+        ops.linear(rnd((8, 64), dev, 9).to(BF16), pw)
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,ups", [
     (2, 16, 16, 64, 128, 1, False), (1, 32, 32, 320, 320, 1, False), (2, 16, 16, 128, 128, 2, False),
     (2, 8, 8, 64, 64, 1, True), (2, 12, 20, 192, 96, 1, False), (1, 9, 7, 64, 32, 2, False),

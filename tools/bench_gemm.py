@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of sdmi_gemm on the shapes of the SD2 path (development aid).
-usage: python tools/bench_gemm.py [iters]   -> one line per shape: us, TFLOP/s"""
+usage: python tools/bench_gemm.py [iters] [conv|lin]   -> one line per shape: us, TFLOP/s
+env TILE_N=128 forces the 128-column tile; SPLITK=<n> forces the split-K factor; SWEEP=1 tries several of each."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,9 +18,17 @@ SHAPES = [  # kind, args
     ("lin", (65536, 320, 320)), ("lin", (65536, 2560, 320)), ("lin", (65536, 320, 1280)), ("lin", (16384, 640, 640)),
     ("lin", (16384, 5120, 640)), ("lin", (4096, 1280, 1280)), ("lin", (4096, 10240, 1280)), ("lin", (8192, 8192, 8192)),
 ]
-for kind, a in SHAPES:
+SHAPES += [("conv", (16, 16, 16, 2560, 1280)), ("conv", (16, 8, 8, 2560, 1280)), ("conv", (16, 32, 32, 1280, 640)),
+           ("conv", (16, 64, 64, 960, 320))]
+auto_split, auto_tile = ops._auto_split_k, ops._tile_n_for
+configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"))]
+if os.environ.get("SWEEP"):
+    configs = [(t, s) for t in ("128", None) for s in (None, "1", "2", "3", "4", "8")]
+for (kind, a), (tile, split) in [(sh, c) for sh in SHAPES for c in configs]:
     if only and only != kind:
         continue
+    ops._tile_n_for = (lambda n, geglu=False: 128) if tile == "128" else auto_tile
+    ops._auto_split_k = (lambda m, n, k, t=128, s_=split: min(int(s_), k // 128)) if split else auto_split
     if kind == "conv":
         b, h, w, cin, cout = a
         x = torch.randn(b, h, w, cin, device=dev).to(BF16)
@@ -43,4 +52,5 @@ for kind, a in SHAPES:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
-    print(f"{kind:5s} {str(a):32s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+    print(f"{kind:5s} {str(a):32s} tile_n={pw.tile_n} split={split or 'auto'} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s",
+          flush=True)
