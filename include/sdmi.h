@@ -92,10 +92,13 @@ typedef struct sdmi_gemm_args {
     int32_t dtype;                      /* sdmi_dtype of A, A2, W, res and of out when out_kind == 0 */
     float alpha;
     int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it */
+    int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 */
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
+/* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
+int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) [+ SiLU] over an NHWC bf16 tensor, fp32 statistics.

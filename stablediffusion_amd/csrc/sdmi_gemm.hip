@@ -22,15 +22,72 @@
 
 namespace {
 
-// 16 bytes of zeros: the DMA source of padded rows / out-of-image taps
-__device__ const uint4 sdmi_zero16 = {0u, 0u, 0u, 0u};
+// Zeros: the DMA source of out-of-image conv taps and padded rows / columns (the DMA cannot mask).  Long enough
+// that a tap's pointer can walk a whole channel run (Cin <= ZERO_ELEMS) without leaving it.
+constexpr int ZERO_ELEMS = 8192;
+__device__ const uint4 sdmi_zeros[ZERO_ELEMS / 8 + 1] = {};
+
+// ---- LDS-DMA issue (global_load_lds_dwordx4, 1 KiB per wave-instruction) ----
+// Issued through inline asm on purpose: with the builtin, hipcc orders every later ds_read behind the DMA
+// (s_waitcnt vmcnt(0) ahead of the MFMAs), which serialises load and compute.  The asm form is invisible to its
+// wait-count pass; the ring is retired by explicit counted s_waitcnt vmcnt(N).  M0 carries the LDS destination:
+// it is saved and restored inside each statement (cdna_hip_programming.md §5.7).  d0 = LDS byte address of this
+// wave's slot in instruction 0 of the stage; instruction i lands O0 + 8192*i bytes further (64 tile rows).
+// "_s": scalar 64-bit base + one 32-bit byte offset per lane;  "_v": a 64-bit pointer per lane.
+#define SDMI_M0_SAVE "s_mov_b32 %[keep], m0\n\t"
+#define SDMI_M0_REST "s_mov_b32 m0, %[keep]"
+#define SDMI_LD_S(N) "s_add_u32 m0, %[d0], %[o" #N "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #N "], %[sb]\n\t"
+#define SDMI_LD_V(N) "s_add_u32 m0, %[d0], %[o" #N "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #N "], off\n\t"
+
+template <int O0>
+__device__ __forceinline__ void glds_s2(unsigned d0, const void* sb, unsigned v0, unsigned v1) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_LD_S(1) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [v1] "v"(v1), [o0] "n"(O0), [o1] "n"(O0 + 8192)
+                 : "memory", "scc");
+}
+template <int O0>
+__device__ __forceinline__ void glds_s3(unsigned d0, const void* sb, unsigned v0, unsigned v1, unsigned v2) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_LD_S(1) SDMI_LD_S(2) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [o0] "n"(O0),
+                   [o1] "n"(O0 + 8192), [o2] "n"(O0 + 16384)
+                 : "memory", "scc");
+}
+template <int O0>
+__device__ __forceinline__ void glds_s4(unsigned d0, const void* sb, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_LD_S(1) SDMI_LD_S(2) SDMI_LD_S(3) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [o0] "n"(O0),
+                   [o1] "n"(O0 + 8192), [o2] "n"(O0 + 16384), [o3] "n"(O0 + 24576)
+                 : "memory", "scc");
+}
+template <int O0>
+__device__ __forceinline__ void glds_v2(unsigned d0, const void* v0, const void* v1) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_V(0) SDMI_LD_V(1) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [v0] "v"(v0), [v1] "v"(v1), [o0] "n"(O0), [o1] "n"(O0 + 8192)
+                 : "memory", "scc");
+}
+template <int O0>
+__device__ __forceinline__ void glds_v4(unsigned d0, const void* v0, const void* v1, const void* v2, const void* v3) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_V(0) SDMI_LD_V(1) SDMI_LD_V(2) SDMI_LD_V(3) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [o0] "n"(O0),
+                   [o1] "n"(O0 + 8192), [o2] "n"(O0 + 16384), [o3] "n"(O0 + 24576)
+                 : "memory", "scc");
+}
 
 // Block tile BM x BN x BK with BN = 32*TN: TN = 4 (128 columns) or TN = 5 (160 columns; every UNet width is a
 // multiple of 160, so those layers lose nothing to column padding).
-constexpr int BM = 128, BK = 64;
-constexpr int NTHREADS = 256;
-constexpr int TILE_CHUNKS = BM * (BK / 8);          // 16-byte chunks per A tile (1024)
-constexpr int lds_bytes(int tn) { return 2 * TILE_CHUNKS * 16 + 2 * (tn * 32) * (BK / 8) * 16; }   // A0 A1 W0 W1
+// and BM = 64*MI: MI = 4 (256 rows) or MI = 2 (128 rows); 8 waves, 3-stage ring, one block per CU.
+constexpr int BK = 64;
+constexpr int lds_bytes(int tn, int mi) { return 3 * (mi * 64 + tn * 32) * (BK / 8) * 16; }
 constexpr int GROUP_M = 8;
 
 struct TileCoord { int tm, tn; };
@@ -113,13 +170,31 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
     }
 }
 
-template <int MODE, int DT, int TN>
-__global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
+// Wait until at most `keep_stages` (0, 1, 2) of this wave's youngest ring stages (PER LDS-DMA instructions each)
+// are still in flight.
+template <int PER>
+__device__ __forceinline__ void wait_dma(int keep_stages) {
+    if (keep_stages >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
+    else if (keep_stages == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+    else                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One workgroup = 8 waves (4 x 2), block tile (64*MI) x (32*TN) x 64, one workgroup per CU (two waves per SIMD),
+// 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
+template <int MODE, int DT, int TN, int MI>
+__global__ __launch_bounds__(512, 1) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
+    constexpr int NST = 3;
+    constexpr int BM = 64 * MI;                 // 4 waves across M, MI 16-row blocks each
     constexpr int BN = TN * 32;                 // 2 waves across N, TN 16-column blocks each
+    constexpr int A_CHUNKS = BM * (BK / 8);     // 16-byte chunks per A tile
     constexpr int W_CHUNKS = BN * (BK / 8);     // 16-byte chunks per W tile
+    constexpr int STAGE_CHUNKS = A_CHUNKS + W_CHUNKS;
+    constexpr int RPI = 64;                     // tile rows one DMA instruction of the whole block covers
+    constexpr int NA = BM / RPI;                // A instructions per thread and stage (4 | 2)
+    constexpr int NW = BN / RPI;                // W instructions every thread issues (2)
+    constexpr bool W_TAIL = (BN % RPI) != 0;    // leftover 32 W rows (TN = 5): waves 0..3 issue one more
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* const As = reinterpret_cast<uint4*>(smem);
-    uint4* const Ws = reinterpret_cast<uint4*>(smem) + 2 * TILE_CHUNKS;
+    const uint4* const lds = reinterpret_cast<const uint4*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -149,19 +224,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     const unsigned short* const A2 = reinterpret_cast<const unsigned short*>(p.A2);
     const unsigned short* const W = reinterpret_cast<const unsigned short*>(p.W) + zoff_w;
 
-    // ---- loader geometry: thread owns 16-byte chunk `lc` of rows lr + 32*i ----
-    const int lr = tid >> 3;                    // tile rows lr + 32*i
+    // ---- loader geometry: thread owns 16-byte chunk `lc` of rows lr + 64*i ----
+    // A wave-instruction writes LDS at (wave-uniform base) + lane*16, i.e. 8 consecutive tile rows x 8 physical
+    // chunks.  The XOR swizzle therefore goes on the SOURCE address: lane l owns physical chunk l&7 of row
+    // 64*i + 8*wave + (l>>3) and fetches logical chunk (l&7) ^ (row&7).
+    const int lr = tid >> 3;                    // tile rows lr + 64*i
     const int lc = (tid & 7) ^ (lr & 7);        // LOGICAL 16-byte chunk fetched into physical chunk tid&7
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    const bool w_tail_wave = W_TAIL && wave_u < (BN - NW * RPI) / 8;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned d_wave = lds_base + wave_u * 1024;
+    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(sdmi_zeros);
+    const int64_t k_valid = p.k_valid > 0 ? p.k_valid : p.K;
 
-    int64_t a_off[4];      // MODE 0: m * lda (and m*lda2 recomputed);  MODE 1: pixel base b*H*W
-    int iy0[4], ix0[4];    // MODE 1
-    bool rvalid[4];
+    // W: scalar base (tile row n0, k-tile) + constant per-lane byte offsets
+    const unsigned short* const w_tile = W + n0 * p.K;
+    unsigned w_voff[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + lr + 32 * i;
+    for (int i = 0; i < 3; ++i) w_voff[i] = (unsigned)((((int64_t)lr + RPI * i) * p.K + lc * 8) * 2);
+
+    // A, mode 0: scalar base (tile row m0, k-tile) + constant per-lane byte offsets; rows past M re-read row M-1
+    // (their results are never stored).  A k-tile that crosses k_valid takes the general path below.
+    unsigned a_voff[NA], a2_voff[NA];
+    // A, general path and conv
+    int64_t a_off[NA];      // MODE 0: row m;  MODE 1: pixel base b*H*W
+    int iy0[NA], ix0[NA];   // MODE 1
+    bool rvalid[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int64_t m = m0 + lr + RPI * i;
         rvalid[i] = m < p.M;
         if (MODE == 0) {
             a_off[i] = m;
+            const int64_t rrel = (rvalid[i] ? m : p.M - 1) - m0;
+            a_voff[i] = (unsigned)((rrel * p.lda + lc * 8) * 2);
+            a2_voff[i] = (unsigned)((rrel * p.lda2 + lc * 8) * 2);
         } else {
             const int64_t hw = (int64_t)p.Ho * p.Wo;
             const int64_t b = m / hw;
@@ -172,134 +269,183 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
             ix0[i] = ox * p.stride - 1;
         }
     }
-    const int64_t k_valid = p.k_valid > 0 ? p.k_valid : p.K;
     const int Hl = p.H << p.upsample, Wl = p.W_in << p.upsample;
-    // conv k-state for this thread's chunk: k = kt*64 + lc*8 -> (tap, ci)
+    // Conv with Cin % 64 == 0: a k-tile never straddles a tap, so (tap, channel run) is one scalar state per wave
+    // and each row keeps a 64-bit pointer that is rebuilt when the tap changes and bumped by 64 channels otherwise.
+    const bool conv_fast = MODE == 1 && (p.Cin % BK) == 0 && p.Cin <= ZERO_ELEMS;
+    int f_tap = 0, f_ci = 0;
+    bool f_new_tap = true;
+    const unsigned short* a_ptr[NA];
+    // general conv path: per-lane (tap, ci) of this thread's chunk, k = kt*64 + lc*8
     int c_tap = 0, c_ci = 0;
     if (MODE == 1) {
+        f_tap = (kt_begin * BK) / p.Cin;
+        f_ci = kt_begin * BK - f_tap * p.Cin;
         const int k = kt_begin * BK + lc * 8;
         c_tap = k / p.Cin;
         c_ci = k - c_tap * p.Cin;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_ptr[i] = zsrc;
     }
 
-    const unsigned short* w_ptr = W + (n0 + lr) * p.K + (int64_t)kt_begin * BK + lc * 8;
-    const int64_t w_row32 = 32 * p.K;
-
-    // ---- staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction) ----
-    // A wave-instruction writes LDS at (wave-uniform base) + lane*16, i.e. 8 consecutive tile rows x 8 physical
-    // chunks.  The XOR swizzle therefore goes on the SOURCE address: lane l owns physical chunk l&7 of row
-    // 32*i + 8*wave + (l>>3) and fetches logical chunk (l&7) ^ (row&7) (set up above as `lc`).  Rows / taps that
-    // must read as zero fetch from a 16-byte zero constant instead (the DMA cannot mask).
-    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(&sdmi_zero16);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
-    // Issued through inline asm on purpose: with the builtin, hipcc orders every later ds_read of the tile
-    // being computed behind the DMA of the NEXT tile (s_waitcnt vmcnt(0) ahead of the MFMAs), which serialises
-    // load and compute.  The asm form is invisible to its wait-count pass; the DMA is retired by the explicit
-    // s_waitcnt vmcnt(0) in front of the barrier that ends the k-step.  M0 (LDS destination) is written and
-    // restored inside the statement (cdna_hip_programming.md §5.7).
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-#define SDMI_GLDS(SRC, LDSBYTE)                                                                            \
+    // general path: one load per statement, 64-bit pointer, zero source where masked
+#define SDMI_GLDS(SRC, D0, OFF)                                                                            \
     do {                                                                                                   \
         unsigned keep_;                                                                                    \
         const void* src_ = (SRC);                                                                          \
-        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + (LDSBYTE));                        \
+        const unsigned dst_ = (D0) + (OFF);                                                                \
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                              \
                      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                                 \
                      : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                    \
     } while (0)
-    // LDS byte offset of instruction i of this wave inside one operand tile: (256*i + 64*wave) chunks
-#define SDMI_TILE_OFF(I) (((256 * (I)) + 64 * wave_u) * 16)
-
-#define SDMI_STAGE_A0(I, KK, BASE, LD, BUFBYTE)                                                            \
-    SDMI_GLDS((rvalid[I] && kin_) ? (BASE) + a_off[I] * (LD) + (KK) : zsrc, (BUFBYTE) + SDMI_TILE_OFF(I))
-#define SDMI_STAGE_A1(I, KY, KX, TV, BUFBYTE)                                                              \
+#define SDMI_STAGE_A0(I, KK, BASE, LD, D0)                                                                 \
+    SDMI_GLDS((rvalid[I] && kin_) ? (BASE) + a_off[I] * (LD) + (KK) : zsrc, D0, 8192 * (I))
+#define SDMI_STAGE_A1(I, KY, KX, TV, D0)                                                                   \
     do {                                                                                                   \
         int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                      \
         const bool ok_ = (TV) && (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;             \
         iy_ >>= p.upsample; ix_ >>= p.upsample;                                                            \
         const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin + c_ci;                      \
-        SDMI_GLDS(ok_ ? A + off_ : zsrc, (BUFBYTE) + SDMI_TILE_OFF(I));                                    \
+        SDMI_GLDS(ok_ ? A + off_ : zsrc, D0, 8192 * (I));                                                  \
+    } while (0)
+#define SDMI_TAP_PTR(I, KY, KX)                                                                            \
+    do {                                                                                                   \
+        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                      \
+        const bool ok_ = (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;                     \
+        iy_ >>= p.upsample; ix_ >>= p.upsample;                                                            \
+        const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin;                             \
+        a_ptr[I] = (ok_ ? A + off_ : zsrc) + (f_ci + lc * 8);                                              \
     } while (0)
 
-    // Issue the DMA of k-tile KT into buffer BUF (A tile at BUF*16 KiB, W tile at 32 KiB + BUF*16 KiB).
+    // Issue this wave's share of the DMA of k-tile KT into ring stage BUF (A tile first, W tile behind it).
 #define SDMI_STAGE_TILE(KT, BUF)                                                                           \
     do {                                                                                                   \
-        const int abyte_ = (BUF) * (TILE_CHUNKS * 16);                                                     \
-        const int wbyte_ = 2 * (TILE_CHUNKS * 16) + (BUF) * (W_CHUNKS * 16);                               \
+        const unsigned d0_ = d_wave + (BUF) * (STAGE_CHUNKS * 16);                                         \
+        const int64_t k0_ = (int64_t)(KT) * BK;                                                            \
         if (MODE == 0) {                                                                                   \
-            const int64_t k_ = (int64_t)(KT) * BK + lc * 8;                                                \
-            const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */       \
-            const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                     \
-            const unsigned short* base_ = second_ ? A2 : A;                                                \
-            const int64_t ld_ = second_ ? p.lda2 : p.lda;                                                  \
-            const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                             \
-            SDMI_STAGE_A0(0, kk_, base_, ld_, abyte_); SDMI_STAGE_A0(1, kk_, base_, ld_, abyte_);          \
-            SDMI_STAGE_A0(2, kk_, base_, ld_, abyte_); SDMI_STAGE_A0(3, kk_, base_, ld_, abyte_);          \
+            if (k0_ + BK <= k_valid) {                                                                     \
+                const bool second_ = (A2 != nullptr) && (k0_ >= p.k_split);                                \
+                const unsigned short* sa_ = second_ ? A2 + m0 * p.lda2 + (k0_ - p.k_split) : A + m0 * p.lda + k0_; \
+                if (NA == 4)                                                                               \
+                    glds_s4<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[1] : a_voff[1], \
+                               second_ ? a2_voff[NA - 2] : a_voff[NA - 2], second_ ? a2_voff[NA - 1] : a_voff[NA - 1]); \
+                else                                                                                       \
+                    glds_s2<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[1] : a_voff[1]); \
+            } else {                                                                                       \
+                const int64_t k_ = k0_ + lc * 8;                                                           \
+                const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */   \
+                const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                 \
+                const unsigned short* base_ = second_ ? A2 : A;                                            \
+                const int64_t ld_ = second_ ? p.lda2 : p.lda;                                              \
+                const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                         \
+                SDMI_STAGE_A0(0, kk_, base_, ld_, d0_); SDMI_STAGE_A0(1, kk_, base_, ld_, d0_);            \
+                if (NA == 4) { SDMI_STAGE_A0(NA - 2, kk_, base_, ld_, d0_); SDMI_STAGE_A0(NA - 1, kk_, base_, ld_, d0_); } \
+            }                                                                                              \
+        } else if (conv_fast) {                                                                            \
+            if (f_new_tap) {                                                                               \
+                const int ky_ = f_tap / 3, kx_ = f_tap - 3 * ky_;                                          \
+                SDMI_TAP_PTR(0, ky_, kx_); SDMI_TAP_PTR(1, ky_, kx_);                                      \
+                if (NA == 4) { SDMI_TAP_PTR(NA - 2, ky_, kx_); SDMI_TAP_PTR(NA - 1, ky_, kx_); }           \
+            }                                                                                              \
+            if (NA == 4) glds_v4<0>(d0_, a_ptr[0], a_ptr[1], a_ptr[NA - 2], a_ptr[NA - 1]);                \
+            else         glds_v2<0>(d0_, a_ptr[0], a_ptr[1]);                                              \
+            _Pragma("unroll")                                                                              \
+            for (int i_ = 0; i_ < NA; ++i_) a_ptr[i_] += BK;                                               \
+            f_ci += BK;                                                                                    \
+            f_new_tap = f_ci == p.Cin;                                                                     \
+            if (f_new_tap) { f_ci = 0; ++f_tap; }                                                          \
         } else {                                                                                           \
             const int ky_ = c_tap / 3, kx_ = c_tap - 3 * ky_;                                              \
             const bool tapvalid_ = c_tap < 9;                                                              \
-            SDMI_STAGE_A1(0, ky_, kx_, tapvalid_, abyte_); SDMI_STAGE_A1(1, ky_, kx_, tapvalid_, abyte_);  \
-            SDMI_STAGE_A1(2, ky_, kx_, tapvalid_, abyte_); SDMI_STAGE_A1(3, ky_, kx_, tapvalid_, abyte_);  \
+            SDMI_STAGE_A1(0, ky_, kx_, tapvalid_, d0_); SDMI_STAGE_A1(1, ky_, kx_, tapvalid_, d0_);        \
+            if (NA == 4) { SDMI_STAGE_A1(NA - 2, ky_, kx_, tapvalid_, d0_); SDMI_STAGE_A1(NA - 1, ky_, kx_, tapvalid_, d0_); } \
             c_ci += BK;                                                                                    \
             while (c_ci >= p.Cin) { c_ci -= p.Cin; ++c_tap; }                                              \
         }                                                                                                  \
-        SDMI_GLDS(w_ptr, wbyte_ + SDMI_TILE_OFF(0));                                                       \
-        SDMI_GLDS(w_ptr + w_row32, wbyte_ + SDMI_TILE_OFF(1));                                             \
-        SDMI_GLDS(w_ptr + 2 * w_row32, wbyte_ + SDMI_TILE_OFF(2));                                         \
-        SDMI_GLDS(w_ptr + 3 * w_row32, wbyte_ + SDMI_TILE_OFF(3));                                         \
-        if (TN == 5) SDMI_GLDS(w_ptr + 4 * w_row32, wbyte_ + SDMI_TILE_OFF(4));                            \
-        w_ptr += BK;                                                                                       \
+        if (w_tail_wave) glds_s3<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1], w_voff[2]);       \
+        else             glds_s2<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1]);                  \
+    } while (0)
+#define SDMI_WAIT_DMA(KEEP)                                                                                \
+    do {                                                                                                   \
+        if (w_tail_wave) wait_dma<NA + NW + 1>(KEEP); else wait_dma<NA + NW>(KEEP);                        \
     } while (0)
 
-    f32x4 acc[TN][4];   // [ni][mi]
+    f32x4 acc[TN][MI];   // [ni][mi]
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15;
     const int fq = lane >> 4;
-    const int a_base = (wm * 64 + frow) * 8;
-    const int w_base = (wn * (TN * 16) + frow) * 8;
+    const int a_base = (wm * (MI * 16) + frow) * 8;
+    const int w_base = A_CHUNKS + (wn * (TN * 16) + frow) * 8;
 
-    if (kt_begin < kt_end) SDMI_STAGE_TILE(kt_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const int nk = kt_end - kt_begin;
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) SDMI_STAGE_TILE(kt + 1, cur ^ 1);     // DMA of the next tile flies under this tile's MFMAs
-        const uint4* Ab = As + cur * TILE_CHUNKS;
-        const uint4* Wb = Ws + cur * W_CHUNKS;
+    // ---- main loop ----
+    // Software pipeline over half k-tiles so that every barrier is followed by MFMA work whose operands are
+    // already in registers: after the barrier that publishes tile t+1 the wave issues the ds_reads of its first
+    // half (f0), runs the held-back second-half MFMAs of tile t (f1, read before the barrier), issues its DMA
+    // share of tile t+3 into the stage tile t just vacated, reads the second half of tile t+1 and runs its
+    // first-half MFMAs.  Ring: tile t+1 being read, t+2 landed or landing, t+3 in flight.
+    uint4 af0[MI], wf0[TN], af1[MI], wf1[TN];
+#define SDMI_READ_FRAGS(AF, WF, STAGE, KS)                                                                 \
+    do {                                                                                                   \
+        const uint4* St_ = lds + (STAGE) * STAGE_CHUNKS;                                                   \
+        const int pc_ = ((KS) * 4 + fq) ^ (frow & 7);                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) AF[i_] = St_[a_base + i_ * 128 + pc_];           \
+        _Pragma("unroll") for (int i_ = 0; i_ < TN; ++i_) WF[i_] = St_[w_base + i_ * 128 + pc_];           \
+    } while (0)
+#define SDMI_MFMA_HALF(AF, WF)                                                                             \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int ni_ = 0; ni_ < TN; ++ni_)                                               \
+            _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
+                acc[ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[ni_][mi_]);                               \
+    } while (0)
+
+    int kt_issue = 0;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pc = (ks * 4 + fq) ^ (frow & 7);
-            uint4 af[4], wf[TN];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = Ab[a_base + i * 128 + pc];
-#pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = Wb[w_base + i * 128 + pc];
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = mfma16<DT>(wf[ni], af[mi], acc[ni][mi]);
+    for (int st = 0; st < NST; ++st) {
+        if (kt_issue < nk) {
+            SDMI_STAGE_TILE(kt_begin + kt_issue, st);
+            ++kt_issue;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of tile kt+1 has landed
-        __syncthreads();                                     // ... and everyone's; buffer `cur` is free again
+    }
+    if (nk > 0) {
+        SDMI_WAIT_DMA(kt_issue - 1);                 // tile 0 has landed (this wave's share)
+        __syncthreads();                             // ... and everyone's
+        SDMI_READ_FRAGS(af0, wf0, 0, 0);
+        SDMI_READ_FRAGS(af1, wf1, 0, 1);
+        SDMI_MFMA_HALF(af0, wf0);
+        int rd = 1, wr = 0;                          // ring stage of tile kt+1 / of tile kt (free after the barrier)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            SDMI_WAIT_DMA(kt_issue - kt - 2);        // tile kt+1 landed; younger tiles may still fly
+            __syncthreads();                         // every wave has finished READING tile kt as well
+            SDMI_READ_FRAGS(af0, wf0, rd, 0);
+            SDMI_MFMA_HALF(af1, wf1);                // second half of tile kt
+            if (kt_issue < nk) {
+                SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
+                ++kt_issue;
+            }
+            SDMI_READ_FRAGS(af1, wf1, rd, 1);
+            SDMI_MFMA_HALF(af0, wf0);                // first half of tile kt+1
+            wr = rd;
+            rd = rd == NST - 1 ? 0 : rd + 1;
+        }
+        SDMI_MFMA_HALF(af1, wf1);                    // second half of the last tile
     }
 
     // ---- epilogue ----
-    // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*64 + mi*16 + (lane&15),
+    // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*16*MI + mi*16 + (lane&15),
     // weight row (column of out) wcol = n0 + wn*16*TN + ni*16 + 4*(lane>>4) + j.
     if (p.split_k > 1) {
         // raw partial sums to the workspace slab of this slice: [split][M][tiles_n*BN] fp32
         float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)z * p.M * ((int64_t)tiles_n * BN);
         const int64_t ldw = (int64_t)tiles_n * BN;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int64_t m = m0 + wm * 64 + mi * 16 + frow;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
             if (m >= p.M) continue;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
@@ -311,8 +457,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void sdmi_gemm_kernel(const sdmi_gemm_
     }
 
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int64_t m = m0 + wm * 64 + mi * 16 + frow;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
         if (m >= p.M) continue;
         if (p.geglu) {
 #pragma unroll
@@ -387,6 +533,15 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
 
 }  // namespace
 
+// Row tile the launcher picks: 256 rows once that still gives every CU a block, else 128 rows.
+static int pick_tile_m(int64_t M, int64_t N_w, int tile_n, int64_t problems) {
+    const int bn = tile_n == 160 ? 160 : 128;
+    const int64_t tiles = ((M + 255) / 256) * ((N_w + bn - 1) / bn) * problems;
+    return tiles >= 256 ? 256 : 128;
+}
+
+extern "C" int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n) { return pick_tile_m(M, N_w, tile_n, 1); }
+
 static int64_t slab_ld(int64_t N_w, int tile_n) { return (N_w + tile_n - 1) / tile_n * tile_n; }
 
 extern "C" int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k) {
@@ -437,6 +592,8 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const int BN = p.tile_n == 0 ? 128 : p.tile_n;
     if (BN != 128 && BN != 160) return SDMI_ERR_BAD_ARG;
     if (BN == 160 && p.geglu) return SDMI_ERR_BAD_ARG;      // GEGLU pairs 16-column blocks inside a wave
+    if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
+    const int BM = p.tile_m != 0 ? p.tile_m : pick_tile_m(p.M, n_w, BN, batch);
     const int64_t tiles_m = (p.M + BM - 1) / BM, tiles_n = (n_w + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
     if (split > 1) {
@@ -446,22 +603,26 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     typedef void (*kern_t)(const sdmi_gemm_args);
-    static const kern_t kernels[2][2][2] = {     // [mode][dtype][tile_n == 160]
-        {{sdmi_gemm_kernel<0, 0, 4>, sdmi_gemm_kernel<0, 0, 5>}, {sdmi_gemm_kernel<0, 1, 4>, sdmi_gemm_kernel<0, 1, 5>}},
-        {{sdmi_gemm_kernel<1, 0, 4>, sdmi_gemm_kernel<1, 0, 5>}, {sdmi_gemm_kernel<1, 1, 4>, sdmi_gemm_kernel<1, 1, 5>}}};
+#define SDMI_K(MODE, DT) {{sdmi_gemm_kernel<MODE, DT, 4, 2>, sdmi_gemm_kernel<MODE, DT, 4, 4>}, \
+                          {sdmi_gemm_kernel<MODE, DT, 5, 2>, sdmi_gemm_kernel<MODE, DT, 5, 4>}}
+    static const kern_t kernels[2][2][2][2] = {     // [mode][dtype][tile_n == 160][tile_m == 256]
+        {SDMI_K(0, 0), SDMI_K(0, 1)}, {SDMI_K(1, 0), SDMI_K(1, 1)}};
+#undef SDMI_K
     static bool attr_done = false;
     if (!attr_done) {
         for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)  // NOLINT
                 for (int c = 0; c < 2; ++c)
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b][c]),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(c ? 5 : 4));
+                    for (int d = 0; d < 2; ++d)
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b][c][d]),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            lds_bytes(c ? 5 : 4, d ? 4 : 2));
         attr_done = true;
     }
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
-    const int wide = BN == 160;
-    hipLaunchKernelGGL(kernels[p.mode][f16 ? 1 : 0][wide], grid, dim3(NTHREADS), lds_bytes(wide ? 5 : 4), s, p);
+    const int wide = BN == 160, tall = BM == 256;
+    hipLaunchKernelGGL(kernels[p.mode][f16 ? 1 : 0][wide][tall], grid, dim3(512), lds_bytes(wide ? 5 : 4, tall ? 4 : 2), s, p);
     SDMI_CHECK_LAUNCH();
     if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);

@@ -53,7 +53,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
             float s[8], ss[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-            for (int64_t pix = p_begin + trow; pix < p_end; pix += rows) {
+            // four pixel rows per trip: the four 16-byte loads are in flight together
+            int64_t pix = p_begin + trow;
+            for (; pix + 3 * rows < p_end; pix += 4 * rows) {
+                uint4 raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix + u * rows, v);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    elem_unpack8<DT>(raw[u], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+                }
+            }
+            for (; pix < p_end; pix += rows) {
                 const uint4 raw = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix, v);
                 float f[8];
                 elem_unpack8<DT>(raw, f);
@@ -68,12 +82,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
         }
     }
     __syncthreads();
+    // per-group totals: 8 threads per group each sum a fixed interleaved subset, then one thread adds the 8
+    __shared__ float part_sum[GN_THREADS / GN_GROUPS][GN_GROUPS][2];
+    {
+        const int g = tid & (GN_GROUPS - 1), part = tid / GN_GROUPS;
+        float S = 0.f, SS = 0.f;
+        for (int e = part; e < rows * cpg; e += GN_THREADS / GN_GROUPS) {
+            const int r = e / cpg, j = e - r * cpg;
+            const float* rowp = sh + (size_t)r * 2 * C;
+            S += rowp[g * cpg + j];
+            SS += rowp[C + g * cpg + j];
+        }
+        part_sum[part][g][0] = S;
+        part_sum[part][g][1] = SS;
+    }
+    __syncthreads();
     if (tid < GN_GROUPS) {
         float S = 0.f, SS = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            const float* rowp = sh + (size_t)r * 2 * C;
-            for (int j = 0; j < cpg; ++j) { S += rowp[tid * cpg + j]; SS += rowp[C + tid * cpg + j]; }
-        }
+        for (int part = 0; part < GN_THREADS / GN_GROUPS; ++part) { S += part_sum[part][tid][0]; SS += part_sum[part][tid][1]; }
         const float n = (float)((p_end - p_begin) * cpg);
         const float mean = S / n;
         float m2 = SS - S * mean;
@@ -145,14 +171,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
         float sc[8], sf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = sh[v * 8 + j]; sf[j] = sh[C + v * 8 + j]; }
-        for (int64_t pix = p_begin + trow; pix < p_end; pix += rows) {
+        int64_t pix = p_begin + trow;
+        for (; pix + 3 * rows < p_end; pix += 4 * rows) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix + u * rows, v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                elem_unpack8<DT>(raw[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = f[j] * sc[j] + sf[j];
+                    f[j] = silu ? silu_f(y) : y;
+                }
+                *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix + u * rows) * C + v * 8) = elem_pack8<DT>(f);
+            }
+        }
+        for (; pix < p_end; pix += rows) {
             const int64_t gp = (int64_t)b * hw + pix;
             const uint4 raw = gn_load(x1, x2, C1, C2, gp, v);
             float f[8];
             elem_unpack8<DT>(raw, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float y = f[j] * sc[j] + sf[j];
+                const float y = f[j] * sc[j] + sf[j];
                 f[j] = silu ? silu_f(y) : y;
             }
             *reinterpret_cast<uint4*>(out + gp * C + v * 8) = elem_pack8<DT>(f);

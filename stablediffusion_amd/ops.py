@@ -130,31 +130,37 @@ def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
 # ----------------------------------------------------------------------------- GEMM family
 
 
-_CUS = 256            # MI355X compute units; two GEMM blocks are co-resident on each
-_PAIR_SLOWDOWN = 1.35  # two co-resident blocks take this long relative to one alone (measured ~1.3-1.4)
+FORCE_TILE_M = 0      # development aid (tools/bench_gemm.py): 0 = the library picks the row tile, else 128 | 256
+
+_CUS = 256            # MI355X compute units; the GEMM kernel runs one 8-wave block per CU at a time
 
 
 @functools.lru_cache(maxsize=None)
-def _auto_split_k(m, n_w, k, tile_n=_BN):
-    """Split-K factor from a small occupancy model, in units of one block k-tile step.  A launch of B blocks
-    puts ceil(B/256) blocks on the busiest CU, which runs them two at a time; each block costs nk/s steps plus
-    a fixed prologue/epilogue; splitting adds the fp32 slab write + the reduce pass.  Constants fitted to
-    tools/bench_gemm.py SWEEP=1 on MI355X (round 1: predicted vs measured within ~5% on the UNet conv shapes)."""
-    tiles = math.ceil(m / 128) * math.ceil(n_w / tile_n)
+def _plan_gemm(m, n_w, k, tile_n=_BN):
+    """(tile_m, split_k) from a small occupancy model, in microseconds.  A launch of B blocks puts ceil(B/256)
+    blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed prologue/epilogue;
+    splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to tools/bench_gemm.py SWEEP=1 on
+    MI355X (predicted vs measured within ~10% on the UNet conv shapes)."""
     nk = k // _BK
-    step_us = 128 * tile_n * _BK * 2 / (2.5e9 / _CUS * 0.29)      # one k-tile step of a lone block, microseconds
-    best, best_cost = 1, None
-    for s in range(1, 17):
-        if s > 1 and nk // s < 2:
-            break
-        per_cu = math.ceil(tiles * s / _CUS)
-        work = math.ceil(nk / s) + 4
-        cost = (per_cu // 2) * _PAIR_SLOWDOWN * work + (per_cu % 2) * work
-        if s > 1:
-            cost += ((2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 3.0) / step_us   # slab write+read (mostly L2/MALL) + launch
-        if best_cost is None or cost < best_cost * 0.97:
-            best, best_cost = s, cost
+    best, best_cost = (128, 1), None
+    for tile_m, step_us in ((256, 1.2 * tile_n / 160), (128, 0.67 * tile_n / 160)):
+        tiles = math.ceil(m / tile_m) * math.ceil(n_w / tile_n)
+        for s in range(1, 17):
+            if s > 1 and nk // s < 2:
+                break
+            blocks = tiles * s
+            cost = math.ceil(blocks / _CUS) * (math.ceil(nk / s) + 4) * step_us
+            if blocks < _CUS:
+                cost *= 0.8 + 0.2 * blocks / _CUS       # a partly idle chip clocks higher and contends less
+            if s > 1:
+                cost += (2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 3.0   # slab write+read (mostly L2/MALL) + launch
+            if best_cost is None or cost < best_cost * 0.97:
+                best, best_cost = (tile_m, s), cost
     return best
+
+
+def _auto_split_k(m, n_w, k, tile_n=_BN):
+    return _plan_gemm(m, n_w, k, tile_n)[1]
 
 
 # Optional per-launch instrumentation (bench.py's roofline leg): when TRACE is a list, every sdmi_gemm
@@ -209,7 +215,10 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.ld_res = res.shape[-1]
     n_w = pw.n_out * (2 if pw.geglu else 1)
     a.tile_n = pw.tile_n
-    sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)
+    a.tile_m, sk = _plan_gemm(m, n_w, pw.k, pw.tile_n)
+    sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)      # (separate hook: tests and tools pin it)
+    if FORCE_TILE_M:
+        a.tile_m = FORCE_TILE_M
     if sk > 1:
         nbytes = hip.lib().sdmi_gemm_workspace_bytes(m, n_w, sk)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)

@@ -120,25 +120,63 @@ def test_split_k(dev):
 
 @pytest.mark.parametrize("n", [160, 320, 200, 960])
 def test_column_tile_variants_agree(dev, n, monkeypatch):
-    """The 128- and 160-column tiles accumulate every output in the same k order: bit-identical results
-    for linear and conv (split-K pinned to 1: the heuristic may split the two tilings differently)."""
+    """The block tilings (128 | 160 columns x 128 | 256 rows, 4- and 3-stage rings) accumulate every output in
+    the same k order: bit-identical results for linear and conv (split-K pinned to 1: the heuristic may split the
+    tilings differently)."""
     ops = _ops()
     monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: 1)
     m, k = 300, 1280
     x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
-    outs = [ops.linear(x.to(BF16), ops.pack_linear(w, b, tile_n=t), out_dtype=torch.float32) for t in (128, 160)]
-    assert torch.equal(outs[0], outs[1])
-    assert rel_err(outs[1], F.linear(q(x), q(w), b)) < 1e-4
-    xi = rnd((2, 8, 8, 64), dev, 4).to(BF16)
+    xi = rnd((2, 24, 8, 64), dev, 4).to(BF16)
     wt, bias = rnd((n, 64, 3, 3), dev, 5, 1 / 24), rnd((n,), dev, 6)
-    outs = [ops.conv3x3(xi, ops.pack_conv3x3(wt, bias, tile_n=t)) for t in (128, 160)]
-    assert torch.equal(outs[0], outs[1])
+    lin, conv = [], []
+    for tile_m in (128, 256):
+        monkeypatch.setattr(ops, "FORCE_TILE_M", tile_m)
+        for t in (128, 160):
+            lin.append(ops.linear(x.to(BF16), ops.pack_linear(w, b, tile_n=t), out_dtype=torch.float32))
+            conv.append(ops.conv3x3(xi, ops.pack_conv3x3(wt, bias, tile_n=t)))
+    for o in lin[1:]:
+        assert torch.equal(lin[0], o)
+    for o in conv[1:]:
+        assert torch.equal(conv[0], o)
+    assert rel_err(lin[0], F.linear(q(x), q(w), b)) < 1e-4
     ref = F.conv2d(xi.float().permute(0, 3, 1, 2), q(wt), bias, padding=1)
-    assert rel_err(outs[1].permute(0, 3, 1, 2), ref) < 6e-3
+    assert rel_err(conv[0].permute(0, 3, 1, 2), ref) < 6e-3
+    monkeypatch.setattr(ops, "FORCE_TILE_M", 0)
     with pytest.raises(Exception):
         pw = ops.pack_geglu(rnd((640, 64), dev, 7), rnd((640,), dev, 8))
         pw.tile_n = 160
         ops.linear(rnd((8, 64), dev, 9).to(BF16), pw)
+
+
+def test_tall_tile_full_path(dev, monkeypatch):
+    """256-row tile on everything the epilogue does: GEGLU, split-K, concat A, emb + residual, stride-2 and
+    upsampling conv, ragged M."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "FORCE_TILE_M", 256)
+    m, c = 700, 320
+    x = rnd((m, c), dev, 1)
+    w, b = rnd((8 * c, c), dev, 2, c ** -0.5), rnd((8 * c,), dev, 3)
+    out = ops.linear(x.to(BF16), ops.pack_geglu(w, b), out_dtype=torch.float32)
+    a, gate = F.linear(q(x), q(w), b).chunk(2, dim=-1)
+    assert rel_err(out, a * F.gelu(gate)) < 1e-4
+    x1, x2 = rnd((m, 640), dev, 4), rnd((m, 320), dev, 5)
+    w2, b2 = rnd((320, 960), dev, 6, 0.03), rnd((320,), dev, 7)
+    res, emb = rnd((m, 320), dev, 8), rnd((7, 320), dev, 9)
+    out = ops.linear(x1.to(BF16), ops.pack_linear(w2, b2), x2=x2.to(BF16), res=res.to(BF16), emb=emb,
+                     rows_per_batch=100, out_dtype=torch.float32)
+    ref = F.linear(torch.cat([q(x1), q(x2)], -1), q(w2), b2) + q(res) + emb.repeat_interleave(100, dim=0)
+    assert rel_err(out, ref) < 1e-4
+    xs, ws, bs = rnd((130, 11520), dev, 10), rnd((1280, 11520), dev, 11, 0.01), rnd((1280,), dev, 12)
+    assert ops._auto_split_k(130, 1280, 11520, 160) > 1
+    out = ops.linear(xs.to(BF16), ops.pack_linear(ws, bs), out_dtype=torch.float32)
+    assert rel_err(out, F.linear(q(xs), q(ws), bs)) < 1e-4
+    for stride, ups in ((2, False), (1, True), (1, False)):
+        xi = rnd((3, 64, 10, 14), dev, 13)
+        wt, bias = rnd((96, 64, 3, 3), dev, 14, 1 / 24), rnd((96,), dev, 15)
+        out = ops.conv3x3(q(xi).permute(0, 2, 3, 1).contiguous().to(BF16), ops.pack_conv3x3(wt, bias), stride=stride, upsample=ups)
+        xin = F.interpolate(q(xi), scale_factor=2, mode="nearest") if ups else q(xi)
+        assert rel_err(out.permute(0, 3, 1, 2), F.conv2d(xin, q(wt), bias, stride=stride, padding=1)) < 6e-3
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,ups", [

@@ -21,10 +21,11 @@ SHAPES = [  # kind, args
 SHAPES += [("conv", (16, 16, 16, 2560, 1280)), ("conv", (16, 8, 8, 2560, 1280)), ("conv", (16, 32, 32, 1280, 640)),
            ("conv", (16, 64, 64, 960, 320))]
 auto_split, auto_tile = ops._auto_split_k, ops._tile_n_for
-configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"))]
+configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
 if os.environ.get("SWEEP"):
-    configs = [(t, s) for t in ("128", None) for s in (None, "1", "2", "3", "4", "8")]
-for (kind, a), (tile, split) in [(sh, c) for sh in SHAPES for c in configs]:
+    configs = [(None, s, tm) for tm in ("128", "256") for s in (None, "1", "2", "4", "8")]
+for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in configs]:
+    ops.FORCE_TILE_M = int(tile_m)
     if only and only != kind:
         continue
     ops._tile_n_for = (lambda n, geglu=False: 128) if tile == "128" else auto_tile
@@ -52,5 +53,5 @@ for (kind, a), (tile, split) in [(sh, c) for sh in SHAPES for c in configs]:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
-    print(f"{kind:5s} {str(a):32s} tile_n={pw.tile_n} split={split or 'auto'} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s",
+    print(f"{kind:5s} {str(a):32s} tile_n={pw.tile_n} tile_m={tile_m} split={split or 'auto'} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s",
           flush=True)
