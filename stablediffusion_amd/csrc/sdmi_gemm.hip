@@ -456,40 +456,119 @@ __global__ __launch_bounds__(512, 1) void sdmi_gemm_kernel(const sdmi_gemm_args 
         return;
     }
 
+    // Common case (no GEGLU, row-major output, N % 4 == 0, column bias): all residual / embedding quads of a row
+    // block are requested before the first one is consumed, so the loads overlap instead of forming one
+    // load -> wait -> store round trip per quad.
+    if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row) {
+        const int64_t ncol0 = n0 + wn * (TN * 16) + 4 * fq;
+        f32x4 bq[TN];
+        bool nval[TN];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
-        if (m >= p.M) continue;
-        if (p.geglu) {
+        for (int ni = 0; ni < TN; ++ni) {
+            const int64_t n = ncol0 + ni * 16;
+            nval[ni] = n < p.N;
+            bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+        const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
 #pragma unroll
-            for (int ni = 0; ni + 1 < TN; ni += 2) {     // GEGLU runs with TN == 4 only (host-checked)
-                const int64_t wcol = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
+            const bool mval = m < p.M;
+            uint2 rq[TN];
+            f32x4 eq[TN];
+            if (p.res != nullptr) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    rq[ni] = make_uint2(0u, 0u);
+                    if (mval && nval[ni]) rq[ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);
+                }
+            }
+            if (p.emb != nullptr) {
+                const float* e = p.emb + (mval ? m / p.rows_per_batch : 0) * p.ld_emb;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    eq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (mval && nval[ni]) eq[ni] = *reinterpret_cast<const f32x4*>(e + ncol0 + ni * 16);
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                if (!(mval && nval[ni])) continue;
+                const int64_t n = ncol0 + ni * 16;
+                f32x4 v = acc[ni][mi] * p.alpha + bq[ni];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+                }
+                if (p.emb != nullptr) v += eq[ni];
+                if (p.res != nullptr) {
+                    float rf[4];
+                    elem_unpack4<DT>(rq[ni], rf);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += rf[j];
+                }
+                if (p.out_kind == 0) {
+                    uint2 ov;
+                    ov.x = elem_pack2<DT>(v[0], v[1]);
+                    ov.y = elem_pack2<DT>(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n) = ov;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n) = v;
+                }
+            }
+        }
+        return;
+    }
+
+    if (p.geglu) {
+        // GEGLU runs with TN == 4 only (host-checked): blocks (0,1) and (2,3) are (value, gate) pairs
+        f32x4 bv[TN / 2], bg[TN / 2];
+#pragma unroll
+        for (int pi = 0; pi < TN / 2; ++pi) {
+            const int64_t wcol = n0 + wn * (TN * 16) + pi * 32 + 4 * fq;
+            bv[pi] = bg[pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && wcol + 19 < 2 * p.N) {
+                bv[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol);
+                bg[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int pi = 0; pi < TN / 2; ++pi) {
+                const int64_t wcol = n0 + wn * (TN * 16) + pi * 32 + 4 * fq;
                 const int64_t n = (wcol >> 5) * 16 + (wcol & 15);
                 if (n >= p.N) continue;
-                f32x4 v = acc[ni][mi] * p.alpha, g = acc[ni + 1][mi] * p.alpha;
-                if (p.bias != nullptr) {
-                    v += *reinterpret_cast<const f32x4*>(p.bias + wcol);
-                    g += *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
-                }
+                f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
                 store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
             }
-        } else {
+        }
+        return;
+    }
+
+    // general path: partial column quads (N % 4 != 0), per-row bias, fp32 NCHW output
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int64_t n = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
-                if (n >= p.N) continue;
-                f32x4 v = acc[ni][mi] * p.alpha;
-                if (p.bias != nullptr && !p.bias_per_row) {
-                    if (n + 3 < p.N) {
-                        v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    } else {
-                        for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
-                    }
+    for (int mi = 0; mi < MI; ++mi) {
+        const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int64_t n = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
+            if (n >= p.N) continue;
+            f32x4 v = acc[ni][mi] * p.alpha;
+            if (p.bias != nullptr && !p.bias_per_row) {
+                if (n + 3 < p.N) {
+                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                } else {
+                    for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
                 }
-                store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
             }
+            store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
         }
     }
 }
