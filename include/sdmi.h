@@ -93,6 +93,8 @@ typedef struct sdmi_gemm_args {
     float alpha;
     int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it */
     int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 */
+    int32_t stages;                     /* LDS ring depth: 0 | 3 = three stages; 2 (128-row tile only) = two stages,
+                                           two blocks per CU - for short K */
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);

@@ -91,17 +91,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
     const int k_idx1 = (sr + 32) * 8 + (sc ^ ((sr >> 1) & 7));     // row sr+32: ((sr+32)>>1)&7 == (sr>>1)&7
     const int v_idx0 = sr * 8 + (sc ^ (((sr >> 1) & 1) << 2));
     const int v_idx1 = (sr + 32) * 8 + (sc ^ (((sr >> 1) & 1) << 2));
-#define ATTN_STORE_TILE(BUF)                                                                   \
+#define ATTN_STORE_TILE(BUF, FULL)                                                             \
     do {                                                                                       \
-        Ks[(BUF) * TILE_CH + k_idx0] = zero_unless(rk0, ok0);                                  \
-        Ks[(BUF) * TILE_CH + k_idx1] = zero_unless(rk1, ok1);                                  \
-        Vs[(BUF) * TILE_CH + v_idx0] = zero_unless(rv0, ok0);                                  \
-        Vs[(BUF) * TILE_CH + v_idx1] = zero_unless(rv1, ok1);                                  \
+        if (FULL) {   /* uniform: every key of the tile exists, nothing to zero */             \
+            Ks[(BUF) * TILE_CH + k_idx0] = rk0;                                                \
+            Ks[(BUF) * TILE_CH + k_idx1] = rk1;                                                \
+            Vs[(BUF) * TILE_CH + v_idx0] = rv0;                                                \
+            Vs[(BUF) * TILE_CH + v_idx1] = rv1;                                                \
+        } else {                                                                               \
+            Ks[(BUF) * TILE_CH + k_idx0] = zero_unless(rk0, ok0);                              \
+            Ks[(BUF) * TILE_CH + k_idx1] = zero_unless(rk1, ok1);                              \
+            Vs[(BUF) * TILE_CH + v_idx0] = zero_unless(rv0, ok0);                              \
+            Vs[(BUF) * TILE_CH + v_idx1] = zero_unless(rv1, ok1);                              \
+        }                                                                                      \
     } while (0)
 
     const int ntiles = (p.Nk + KB - 1) / KB;
     ATTN_LOAD_TILE(0);
-    ATTN_STORE_TILE(0);
+    ATTN_STORE_TILE(0, KB <= p.Nk);
     __syncthreads();
 
     // transposed-read lane geometry (ds_read_b64_tr_b16, per 16-lane group):
@@ -157,8 +164,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
         }
         l_run = l_run * alpha + psum;     // per-lane partial (this lane's 32 of the 64 keys)
         m_run = m_new;
+        // rescale the running output only when some query of the wave saw a new maximum (rare after the first tiles)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) 
                 }
             }
         }
-        if (t + 1 < ntiles) ATTN_STORE_TILE(cur ^ 1);
+        if (t + 1 < ntiles) ATTN_STORE_TILE(cur ^ 1, (t + 2) * KB <= p.Nk);
         __syncthreads();
     }
 

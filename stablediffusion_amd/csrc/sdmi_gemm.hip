@@ -87,7 +87,7 @@ __device__ __forceinline__ void glds_v4(unsigned d0, const void* v0, const void*
 // multiple of 160, so those layers lose nothing to column padding).
 // and BM = 64*MI: MI = 4 (256 rows) or MI = 2 (128 rows); 8 waves, 3-stage ring, one block per CU.
 constexpr int BK = 64;
-constexpr int lds_bytes(int tn, int mi) { return 3 * (mi * 64 + tn * 32) * (BK / 8) * 16; }
+constexpr int lds_bytes(int tn, int mi, int nst) { return nst * (mi * 64 + tn * 32) * (BK / 8) * 16; }
 constexpr int GROUP_M = 8;
 
 struct TileCoord { int tm, tn; };
@@ -181,9 +181,8 @@ __device__ __forceinline__ void wait_dma(int keep_stages) {
 
 // One workgroup = 8 waves (4 x 2), block tile (64*MI) x (32*TN) x 64, one workgroup per CU (two waves per SIMD),
 // 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
-template <int MODE, int DT, int TN, int MI>
-__global__ __launch_bounds__(512, 1) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
-    constexpr int NST = 3;
+template <int MODE, int DT, int TN, int MI, int NST>
+__global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
     constexpr int BM = 64 * MI;                 // 4 waves across M, MI 16-row blocks each
     constexpr int BN = TN * 32;                 // 2 waves across N, TN 16-column blocks each
     constexpr int A_CHUNKS = BM * (BK / 8);     // 16-byte chunks per A tile
@@ -672,6 +671,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (BN != 128 && BN != 160) return SDMI_ERR_BAD_ARG;
     if (BN == 160 && p.geglu) return SDMI_ERR_BAD_ARG;      // GEGLU pairs 16-column blocks inside a wave
     if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
+    if (p.stages != 0 && p.stages != 2 && p.stages != 3) return SDMI_ERR_BAD_ARG;
     const int BM = p.tile_m != 0 ? p.tile_m : pick_tile_m(p.M, n_w, BN, batch);
     const int64_t tiles_m = (p.M + BM - 1) / BM, tiles_n = (n_w + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
@@ -682,26 +682,30 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     typedef void (*kern_t)(const sdmi_gemm_args);
-#define SDMI_K(MODE, DT) {{sdmi_gemm_kernel<MODE, DT, 4, 2>, sdmi_gemm_kernel<MODE, DT, 4, 4>}, \
-                          {sdmi_gemm_kernel<MODE, DT, 5, 2>, sdmi_gemm_kernel<MODE, DT, 5, 4>}}
-    static const kern_t kernels[2][2][2][2] = {     // [mode][dtype][tile_n == 160][tile_m == 256]
-        {SDMI_K(0, 0), SDMI_K(0, 1)}, {SDMI_K(1, 0), SDMI_K(1, 1)}};
+    // [mode][dtype][tile_n == 160][variant]: variant 0 = 128 rows / 3 stages, 1 = 256 rows / 3 stages,
+    // 2 = 128 rows / 2 stages (64-72 KiB of LDS: two blocks per CU, for short K where the epilogue of one block
+    // should overlap the main loop of another)
+#define SDMI_K(MODE, DT) {{sdmi_gemm_kernel<MODE, DT, 4, 2, 3>, sdmi_gemm_kernel<MODE, DT, 4, 4, 3>, sdmi_gemm_kernel<MODE, DT, 4, 2, 2>}, \
+                          {sdmi_gemm_kernel<MODE, DT, 5, 2, 3>, sdmi_gemm_kernel<MODE, DT, 5, 4, 3>, sdmi_gemm_kernel<MODE, DT, 5, 2, 2>}}
+    static const kern_t kernels[2][2][2][3] = {{SDMI_K(0, 0), SDMI_K(0, 1)}, {SDMI_K(1, 0), SDMI_K(1, 1)}};
 #undef SDMI_K
     static bool attr_done = false;
     if (!attr_done) {
         for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b)  // NOLINT
+            for (int b = 0; b < 2; ++b)
                 for (int c = 0; c < 2; ++c)
-                    for (int d = 0; d < 2; ++d)
+                    for (int d = 0; d < 3; ++d)
                         hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b][c][d]),
                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            lds_bytes(c ? 5 : 4, d ? 4 : 2));
+                                            lds_bytes(c ? 5 : 4, d == 1 ? 4 : 2, d == 2 ? 2 : 3));
         attr_done = true;
     }
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
-    hipLaunchKernelGGL(kernels[p.mode][f16 ? 1 : 0][wide][tall], grid, dim3(512), lds_bytes(wide ? 5 : 4, tall ? 4 : 2), s, p);
+    const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
+    hipLaunchKernelGGL(kernels[p.mode][f16 ? 1 : 0][wide][variant], grid, dim3(512),
+                       lds_bytes(wide ? 5 : 4, tall ? 4 : 2, variant == 2 ? 2 : 3), s, p);
     SDMI_CHECK_LAUNCH();
     if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);

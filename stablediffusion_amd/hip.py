@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("alpha", C.c_float),
         ("tile_n", C.c_int32),
         ("tile_m", C.c_int32),
+        ("stages", C.c_int32),
     ]
 
 

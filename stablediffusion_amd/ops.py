@@ -137,12 +137,16 @@ _CUS = 256            # MI355X compute units; the GEMM kernel runs one 8-wave bl
 
 @functools.lru_cache(maxsize=None)
 def _plan_gemm(m, n_w, k, tile_n=_BN):
-    """(tile_m, split_k) from a small occupancy model, in microseconds.  A launch of B blocks puts ceil(B/256)
+    """(tile_m, split_k, stages) from a small occupancy model, in microseconds.  A launch of B blocks puts ceil(B/256)
     blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed prologue/epilogue;
     splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to tools/bench_gemm.py SWEEP=1 on
     MI355X (predicted vs measured within ~10% on the UNet conv shapes)."""
     nk = k // _BK
-    best, best_cost = (128, 1), None
+    if nk <= 10 and math.ceil(m / 128) * math.ceil(n_w / tile_n) >= 2 * _CUS:
+        # short K, many tiles: 128-row tile with a two-stage ring = two blocks per CU, so the (relatively long)
+        # epilogue of one block overlaps the main loop of the other (bench_gemm: +5..15% over the 256-row tile)
+        return (128, 1, 2)
+    best, best_cost = (128, 1, 3), None
     for tile_m, step_us in ((256, 1.2 * tile_n / 160), (128, 0.67 * tile_n / 160)):
         tiles = math.ceil(m / tile_m) * math.ceil(n_w / tile_n)
         for s in range(1, 17):
@@ -155,7 +159,7 @@ def _plan_gemm(m, n_w, k, tile_n=_BN):
             if s > 1:
                 cost += (2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 3.0   # slab write+read (mostly L2/MALL) + launch
             if best_cost is None or cost < best_cost * 0.97:
-                best, best_cost = (tile_m, s), cost
+                best, best_cost = (tile_m, s, 3), cost
     return best
 
 
@@ -215,10 +219,11 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.ld_res = res.shape[-1]
     n_w = pw.n_out * (2 if pw.geglu else 1)
     a.tile_n = pw.tile_n
-    a.tile_m, sk = _plan_gemm(m, n_w, pw.k, pw.tile_n)
+    a.tile_m, sk, a.stages = _plan_gemm(m, n_w, pw.k, pw.tile_n)
     sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)      # (separate hook: tests and tools pin it)
     if FORCE_TILE_M:
-        a.tile_m = FORCE_TILE_M
+        a.tile_m = FORCE_TILE_M & ~1
+        a.stages = 2 if FORCE_TILE_M & 1 else 3         # 129 = 128 rows, two stages
     if sk > 1:
         nbytes = hip.lib().sdmi_gemm_workspace_bytes(m, n_w, sk)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)

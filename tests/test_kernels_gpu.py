@@ -130,7 +130,7 @@ def test_column_tile_variants_agree(dev, n, monkeypatch):
     xi = rnd((2, 24, 8, 64), dev, 4).to(BF16)
     wt, bias = rnd((n, 64, 3, 3), dev, 5, 1 / 24), rnd((n,), dev, 6)
     lin, conv = [], []
-    for tile_m in (128, 256):
+    for tile_m in (128, 129, 256):
         monkeypatch.setattr(ops, "FORCE_TILE_M", tile_m)
         for t in (128, 160):
             lin.append(ops.linear(x.to(BF16), ops.pack_linear(w, b, tile_n=t), out_dtype=torch.float32))

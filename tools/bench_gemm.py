@@ -20,10 +20,11 @@ SHAPES = [  # kind, args
 ]
 SHAPES += [("conv", (16, 16, 16, 2560, 1280)), ("conv", (16, 8, 8, 2560, 1280)), ("conv", (16, 32, 32, 1280, 640)),
            ("conv", (16, 64, 64, 960, 320))]
+SHAPES += [("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
 auto_split, auto_tile = ops._auto_split_k, ops._tile_n_for
 configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
 if os.environ.get("SWEEP"):
-    configs = [(None, s, tm) for tm in ("128", "256") for s in (None, "1", "2", "4", "8")]
+    configs = [(None, s, tm) for tm in ("128", "129", "256") for s in (None, "1", "2", "4")]
 for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in configs]:
     ops.FORCE_TILE_M = int(tile_m)
     if only and only != kind:
@@ -36,6 +37,12 @@ for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in confi
         pw = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, torch.randn(cout, device=dev))
         fn = lambda: ops.conv3x3(x, pw)
         flops = 2 * b * h * w * cout * 9 * cin
+    elif kind == "geglu":
+        m, inner, k = a
+        x = torch.randn(m, k, device=dev).to(BF16)
+        pw = ops.pack_geglu(torch.randn(2 * inner, k, device=dev) * 0.02, torch.randn(2 * inner, device=dev))
+        fn = lambda: ops.linear(x, pw)
+        flops = 2 * m * 2 * inner * k
     else:
         m, n, k = a
         x = torch.randn(m, k, device=dev).to(BF16)
