@@ -136,8 +136,17 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T):
                 fh.write(" ".join(str(x) for x in key) + f" {n_} {t_ * 1e6:.1f} {f_ / t_ / 1e12:.1f}\n")
     fl, tm, n = out["conv3x3"]
     lf, lt, ln = out["linear"]
+    # HBM-side bytes per conv launch: PMC figures of a separate rocprofv3 run of this same command, committed
+    # under profiles/ (counters cannot be read from inside the process); null when the file is absent
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh)["per_launch_kib"]["conv"]["bytes_per_launch"]
     return {"bound": "mfma", "achieved": fl / tm / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": fl / tm / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": fl / tm / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": "L2-miss bytes per conv launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json); "
+                            "the kernel is MFMA-bound, the figure shows it stays far below the HBM bound",
             "kernel": "sdmi_gemm_kernel<1> (implicit-GEMM conv3x3, bf16 MFMA 16x16x32)",
             "flops_per_launch": fl / n, "avg_launch_us": tm / n * 1e6, "launches_per_step": n,
             "note": "launch time includes the split-K reduce kernel where split-K is used",
