@@ -42,7 +42,7 @@ const char* sdmi_status_str(int status);
 int sdmi_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
- * GEMM / implicit-GEMM convolution on bf16 MFMA (fp32 accumulate):
+ * GEMM / implicit-GEMM convolution on 16-bit (bf16 | f16) MFMA, fp32 accumulate:
  *     out[m, n] = epilogue( alpha * sum_k A[m, k] * W[n, k] )
  * Replaces: nn.Linear at ldm/modules/attention.py:81,117,213,224,291-296 and
  * ldm/modules/diffusion/openai_model.py:218,618-620; nn.Conv2d (3x3 s1/s2, 1x1) at
@@ -64,8 +64,8 @@ int sdmi_abi_version(void);
  * Epilogue, in this order: *alpha, +bias (per column n, or per row m if bias_per_row),
  *   GEGLU (geglu=1: W rows hold [16 value | 16 gate] column blocks alternately, bias packed the
  *   same way; out = value * gelu_erf(gate); N counts gated output columns), act (1 = SiLU),
- *   +emb[m / rows_per_batch, n] (fp32), +res[m, n] (bf16), store as out_kind.
- *   out_kind 0: bf16 [M, ld_out]; 1: fp32 [M, ld_out]; 2: fp32 NCHW [M/rows_per_batch, N, rows_per_batch].
+ *   +emb[m / rows_per_batch, n] (fp32), +res[m, n] (16-bit), store as out_kind.
+ *   out_kind 0: 16-bit [M, ld_out]; 1: fp32 [M, ld_out]; 2: fp32 NCHW [M/rows_per_batch, N, rows_per_batch].
  * batch > 1 runs `batch` independent problems (grid.z) with the element strides given.
  * split_k > 1 splits K over grid.z (batch must be 1): needs `workspace` of
  *   sdmi_gemm_workspace_bytes() bytes; partial sums are reduced in a second kernel.
@@ -103,7 +103,7 @@ int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);
 
 /* ------------------------------------------------------------------------------------------
- * GroupNorm(32 groups) [+ SiLU] over an NHWC bf16 tensor, fp32 statistics.
+ * GroupNorm(32 groups) [+ SiLU] over an NHWC 16-bit tensor, fp32 statistics.
  * Replaces: GroupNorm32 + nn.SiLU at ldm/utils.py:267-278 with openai_model.py:186-190,
  * 225-235,922-927; nn.GroupNorm(eps 1e-6) at attention.py:45,241; group_norm + swish at
  * model.py:24-40,404-405,458-466,508.
@@ -118,13 +118,13 @@ int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2,
                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw);
 
-/* LayerNorm over the last dim C of a bf16 [rows, C] matrix, fp32 statistics, affine.
+/* LayerNorm over the last dim C of a 16-bit [rows, C] matrix, fp32 statistics, affine.
  * Replaces nn.LayerNorm at attention.py:512-514 (called :525-527).  C % 8 == 0. */
 int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out,
                    int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Flash-style multi-head attention, head dim 64, bf16 in/out, fp32 logits + online softmax.
+ * Flash-style multi-head attention, head dim 64, 16-bit in/out, fp32 logits + online softmax.
  *   out[b, i, h*64 + :] = softmax_j( scale * q[b,i,h,:] . k[b,j,h,:] ) @ v[b,j,h,:]
  * Replaces CrossAttention.forward at attention.py:315-378 (the einsum/softmax/einsum chain and
  * the head split/merge rearranges); never materialises the [B*H, Nq, Nk] score tensor.
@@ -138,7 +138,7 @@ int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out,
 
 /* Row / column softmax helpers for the VAE single-head attention (model.py:514-523), whose
  * score matrix S is produced by sdmi_gemm (out_kind 1).
- *   rows: P[i, j] = softmax_j S[i, j]            (bf16 out)       - "standard" mode
+ *   rows: P[i, j] = softmax_j S[i, j]            (16-bit out)     - "standard" mode
  *   cols: PT[j, i] = softmax_j ST[j, i] for each column i of ST    - "reference" mode, where
  *         ST[j, i] = scale * k_j . q_i, so PT = W^T with W row-normalised over j (model.py:521-523).
  * colstats: fp32 scratch of sdmi_softmax_cols_scratch_bytes(batch, cols) bytes. */
