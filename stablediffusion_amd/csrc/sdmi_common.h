@@ -25,8 +25,14 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+
+// one v_cvt_pk_bf16_f32 (round to nearest even)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
 }
 
 __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
@@ -56,7 +62,12 @@ template <int DT> __device__ __forceinline__ unsigned short elem_from_f32(float 
     else return __builtin_bit_cast(unsigned short, (_Float16)f);
 }
 template <int DT> __device__ __forceinline__ unsigned elem_pack2(float lo, float hi) {
-    return (unsigned)elem_from_f32<DT>(lo) | ((unsigned)elem_from_f32<DT>(hi) << 16);
+    if constexpr (DT == 0) {
+        return pack_bf16x2(lo, hi);
+    } else {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v));   // one v_cvt_pk_f16_f32
+    }
 }
 template <int DT> __device__ __forceinline__ void elem_unpack8(const uint4& v, float* f) {
     if constexpr (DT == 0) {
@@ -71,10 +82,10 @@ template <int DT> __device__ __forceinline__ uint4 elem_pack8(const float* f) {
     if constexpr (DT == 0) {
         return pack_bf16x8(f);
     } else {
-        f16x8 h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (_Float16)f[j];
-        return __builtin_bit_cast(uint4, h);
+        uint4 v;
+        v.x = elem_pack2<1>(f[0], f[1]); v.y = elem_pack2<1>(f[2], f[3]);
+        v.z = elem_pack2<1>(f[4], f[5]); v.w = elem_pack2<1>(f[6], f[7]);
+        return v;
     }
 }
 template <int DT> __device__ __forceinline__ void elem_unpack4(const uint2& v, float* f) {
