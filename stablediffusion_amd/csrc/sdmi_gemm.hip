@@ -20,6 +20,10 @@
 // range of tiles.
 #include "sdmi_common.h"
 
+#ifndef SDMI_SETPRIO
+#define SDMI_SETPRIO 0   // A/B on MI355X (tools/ab_build.sh): raising the wave priority around the MFMA groups gains nothing here
+#endif
+
 namespace {
 
 // Zeros: the DMA source of out-of-image conv taps and padded rows / columns (the DMA cannot mask).  Long enough
@@ -398,9 +402,11 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
     } while (0)
 #define SDMI_MFMA_HALF(AF, WF)                                                                             \
     do {                                                                                                   \
+        if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                   \
         _Pragma("unroll") for (int ni_ = 0; ni_ < TN; ++ni_)                                               \
             _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
                 acc[ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[ni_][mi_]);                               \
+        if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                   \
     } while (0)
 
     int kt_issue = 0;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdmi_hip.so")
+# SDMI_LIB: development override to A/B a differently built library (tools/ab_build.sh)
+LIB_PATH = os.environ.get("SDMI_LIB") or os.path.join(_HERE, "csrc", "libsdmi_hip.so")
 
 SDMI_OK = 0
 DTYPE_BF16, DTYPE_F16 = 0, 1

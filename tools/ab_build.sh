@@ -1,0 +1,11 @@
+#!/bin/bash
+# Development aid: build a second library with extra -D flags for A/B runs, e.g.
+#   tools/ab_build.sh -DSDMI_SETPRIO=0   ->  stablediffusion_amd/csrc/libsdmi_hip_b.so  (use with SDMI_LIB=<path>)
+set -e
+cd "$(dirname "$0")/../stablediffusion_amd/csrc"
+objs=""
+for f in sdmi_api sdmi_gemm sdmi_norm sdmi_elem sdmi_attn; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value "$@" -c $f.hip -o /tmp/ab_$f.o
+  objs="$objs /tmp/ab_$f.o"
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libsdmi_hip_b.so $objs
