@@ -20,6 +20,9 @@
 // range of tiles.
 #include "sdmi_common.h"
 
+#ifndef SDMI_SCHED_INTERLEAVE
+#define SDMI_SCHED_INTERLEAVE 1   // A/B: +1..3% on MI355X
+#endif
 #ifndef SDMI_SETPRIO
 #define SDMI_SETPRIO 0   // A/B on MI355X (tools/ab_build.sh): raising the wave priority around the MFMA groups gains nothing here
 #endif
@@ -409,6 +412,20 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
         if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                   \
     } while (0)
 
+    // scheduling hint for the region just written: one ds_read, then two MFMAs, MI+TN times (spreads the LDS reads
+    // of the next half under the MFMAs of this one instead of bunching them)
+#if SDMI_SCHED_INTERLEAVE
+#define SDMI_INTERLEAVE()                                                                                  \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int g_ = 0; g_ < MI + TN; ++g_) {                                           \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
+        }                                                                                                  \
+    } while (0)
+#else
+#define SDMI_INTERLEAVE() do {} while (0)
+#endif
+
     int kt_issue = 0;
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
@@ -429,12 +446,14 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
             __syncthreads();                         // every wave has finished READING tile kt as well
             SDMI_READ_FRAGS(af0, wf0, rd, 0);
             SDMI_MFMA_HALF(af1, wf1);                // second half of tile kt
+            SDMI_INTERLEAVE();
             if (kt_issue < nk) {
                 SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
                 ++kt_issue;
             }
             SDMI_READ_FRAGS(af1, wf1, rd, 1);
             SDMI_MFMA_HALF(af0, wf0);                // first half of tile kt+1
+            SDMI_INTERLEAVE();
             wr = rd;
             rd = rd == NST - 1 ? 0 : rd + 1;
         }
