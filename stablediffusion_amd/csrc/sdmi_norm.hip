@@ -31,84 +31,6 @@ __device__ __forceinline__ uint4 gn_load(const unsigned short* x1, const unsigne
     return *reinterpret_cast<const uint4*>(x2 + pixel * C2 + (c - C1));
 }
 
-template <int DT>
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned short* __restrict__ x1,
-                                                              const unsigned short* __restrict__ x2, int C1, int C2,
-                                                              int64_t hw, int64_t P, float* __restrict__ partial) {
-    // LDS: per-(thread row) channel sums, [rows][2][C]; summed in a fixed order afterwards (no atomics, so
-    // the result is bit-reproducible from call to call)
-    extern __shared__ __attribute__((aligned(16))) float sh[];
-    const int C = C1 + C2, nvec = C >> 3, cpg = C / GN_GROUPS;
-    const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
-    const int tid = threadIdx.x;
-
-    const int cols = nvec < GN_THREADS ? nvec : GN_THREADS;
-    const int rows = GN_THREADS / cols;
-    const int tcol = tid % cols, trow = tid / cols;
-    const int64_t p_begin = (int64_t)slab * P;
-    const int64_t p_end = (p_begin + P < hw) ? p_begin + P : hw;
-    if (trow < rows) {
-        float* mine = sh + (size_t)trow * 2 * C;
-        for (int v = tcol; v < nvec; v += cols) {
-            float s[8], ss[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-            // four pixel rows per trip: the four 16-byte loads are in flight together
-            int64_t pix = p_begin + trow;
-            for (; pix + 3 * rows < p_end; pix += 4 * rows) {
-                uint4 raw[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) raw[u] = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix + u * rows, v);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float f[8];
-                    elem_unpack8<DT>(raw[u], f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
-                }
-            }
-            for (; pix < p_end; pix += rows) {
-                const uint4 raw = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix, v);
-                float f[8];
-                elem_unpack8<DT>(raw, f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                mine[v * 8 + j] = s[j];
-                mine[C + v * 8 + j] = ss[j];
-            }
-        }
-    }
-    __syncthreads();
-    // per-group totals: 8 threads per group each sum a fixed interleaved subset, then one thread adds the 8
-    __shared__ float part_sum[GN_THREADS / GN_GROUPS][GN_GROUPS][2];
-    {
-        const int g = tid & (GN_GROUPS - 1), part = tid / GN_GROUPS;
-        float S = 0.f, SS = 0.f;
-        for (int e = part; e < rows * cpg; e += GN_THREADS / GN_GROUPS) {
-            const int r = e / cpg, j = e - r * cpg;
-            const float* rowp = sh + (size_t)r * 2 * C;
-            S += rowp[g * cpg + j];
-            SS += rowp[C + g * cpg + j];
-        }
-        part_sum[part][g][0] = S;
-        part_sum[part][g][1] = SS;
-    }
-    __syncthreads();
-    if (tid < GN_GROUPS) {
-        float S = 0.f, SS = 0.f;
-        for (int part = 0; part < GN_THREADS / GN_GROUPS; ++part) { S += part_sum[part][tid][0]; SS += part_sum[part][tid][1]; }
-        const float n = (float)((p_end - p_begin) * cpg);
-        const float mean = S / n;
-        float m2 = SS - S * mean;
-        if (m2 < 0.f) m2 = 0.f;
-        float* o = partial + (((int64_t)b * nslab + slab) * GN_GROUPS + tid) * 3;
-        o[0] = n; o[1] = mean; o[2] = m2;
-    }
-}
-
 // Chan/Welford merge of two (n, mean, M2) summaries; an empty right-hand side leaves the left unchanged.
 __device__ __forceinline__ void gn_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
     if (nb == 0.f) return;
@@ -119,63 +41,42 @@ __device__ __forceinline__ void gn_merge(float& n, float& mean, float& m2, float
     n = tot;
 }
 
+__device__ __forceinline__ int64_t p_begin_of(int slab, int64_t P) { return (int64_t)slab * P; }
+__device__ __forceinline__ int64_t p_end_of(int slab, int64_t P, int64_t hw) {
+    const int64_t e = (int64_t)slab * P + P;
+    return e < hw ? e : hw;
+}
+
+// y = silu?(x * scale[c] + shift[c]) over pixels [p_begin, p_end) x channels [c0, c0 + Cw) of image b; scale/shift
+// tables are built in LDS (sh[2*Cw]) from grp_stat[g_local] = (mean, rstd).  Called by every thread of the block.
 template <int DT>
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned short* __restrict__ x1,
-                                                              const unsigned short* __restrict__ x2, int C1, int C2,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta,
-                                                              const float* __restrict__ partial, float eps,
-                                                              unsigned short* __restrict__ out, int64_t hw, int64_t P,
-                                                              int silu) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // scale[C], shift[C]
-    __shared__ float sub_stat[GN_THREADS / GN_GROUPS][GN_GROUPS][3];
-    __shared__ float grp_stat[GN_GROUPS][2];
-    const int C = C1 + C2, nvec = C >> 3, cpg = C / GN_GROUPS;
-    const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
-    const int tid = threadIdx.x;
-    // Every block merges the slab partials of its image itself (fixed order: 8 interleaved chains per group,
-    // then the 8 chain results in order), which replaces a separate single-block finalize launch.
-    {
-        const int g = tid & (GN_GROUPS - 1), sub = tid / GN_GROUPS;
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int sl = sub; sl < nslab; sl += GN_THREADS / GN_GROUPS) {
-            const float* pp = partial + (((int64_t)b * nslab + sl) * GN_GROUPS + g) * 3;
-            gn_merge(n, mean, m2, pp[0], pp[1], pp[2]);
-        }
-        sub_stat[sub][g][0] = n; sub_stat[sub][g][1] = mean; sub_stat[sub][g][2] = m2;
-    }
-    __syncthreads();
-    if (tid < GN_GROUPS) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int sub = 0; sub < GN_THREADS / GN_GROUPS; ++sub)
-            gn_merge(n, mean, m2, sub_stat[sub][tid][0], sub_stat[sub][tid][1], sub_stat[sub][tid][2]);
-        grp_stat[tid][0] = mean;
-        grp_stat[tid][1] = rsqrtf(m2 / n + eps);
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += GN_THREADS) {
+__device__ __forceinline__ void gn_apply_stream(const unsigned short* __restrict__ x1, const unsigned short* __restrict__ x2,
+                                                int C1, int C2, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, const float* grp_stat,
+                                                unsigned short* __restrict__ out, int64_t hw, int64_t p_begin,
+                                                int64_t p_end, int b, int c0, int Cw, int cpg, int silu, float* sh) {
+    const int C = C1 + C2, tid = threadIdx.x, v0 = c0 >> 3, nvec = Cw >> 3;
+    for (int c = tid; c < Cw; c += GN_THREADS) {
         const int g = c / cpg;
-        const float mean = grp_stat[g][0], rstd = grp_stat[g][1];
-        const float sc = rstd * gamma[c];
+        const float mean = grp_stat[2 * g], rstd = grp_stat[2 * g + 1];
+        const float sc = rstd * gamma[c0 + c];
         sh[c] = sc;
-        sh[C + c] = beta[c] - mean * sc;
+        sh[Cw + c] = beta[c0 + c] - mean * sc;
     }
     __syncthreads();
     const int cols = nvec < GN_THREADS ? nvec : GN_THREADS;
     const int rows = GN_THREADS / cols;
     const int tcol = tid % cols, trow = tid / cols;
     if (trow >= rows) return;
-    const int64_t p_begin = (int64_t)slab * P;
-    const int64_t p_end = (p_begin + P < hw) ? p_begin + P : hw;
     for (int v = tcol; v < nvec; v += cols) {
         float sc[8], sf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = sh[v * 8 + j]; sf[j] = sh[C + v * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { sc[j] = sh[v * 8 + j]; sf[j] = sh[Cw + v * 8 + j]; }
         int64_t pix = p_begin + trow;
         for (; pix + 3 * rows < p_end; pix += 4 * rows) {
             uint4 raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix + u * rows, v);
+            for (int u = 0; u < 4; ++u) raw[u] = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix + u * rows, v0 + v);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float f[8];
@@ -185,12 +86,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
                     const float y = f[j] * sc[j] + sf[j];
                     f[j] = silu ? silu_f(y) : y;
                 }
-                *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix + u * rows) * C + v * 8) = elem_pack8<DT>(f);
+                *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix + u * rows) * C + c0 + v * 8) = elem_pack8<DT>(f);
             }
         }
         for (; pix < p_end; pix += rows) {
             const int64_t gp = (int64_t)b * hw + pix;
-            const uint4 raw = gn_load(x1, x2, C1, C2, gp, v);
+            const uint4 raw = gn_load(x1, x2, C1, C2, gp, v0 + v);
             float f[8];
             elem_unpack8<DT>(raw, f);
 #pragma unroll
@@ -198,9 +99,160 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
                 const float y = f[j] * sc[j] + sf[j];
                 f[j] = silu ? silu_f(y) : y;
             }
-            *reinterpret_cast<uint4*>(out + gp * C + v * 8) = elem_pack8<DT>(f);
+            *reinterpret_cast<uint4*>(out + gp * C + c0 + v * 8) = elem_pack8<DT>(f);
         }
     }
+}
+
+// grid (slabs, nb, gchunks): a block owns P pixels x Cw = C/gchunks channels (32/gchunks whole groups), so that
+// low-resolution tensors (8x8, 16x16: one or four slabs per image) still fill the chip.
+// FUSED (one slab per image: the block sees every pixel of its groups): statistics and apply in ONE launch - the
+// second read of x comes from L2.  Otherwise the block writes its (n, mean, M2) partials for gn_apply_kernel.
+template <int DT, bool FUSED>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned short* __restrict__ x1,
+                                                              const unsigned short* __restrict__ x2, int C1, int C2,
+                                                              int64_t hw, int64_t P, float* __restrict__ partial,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              unsigned short* __restrict__ out, int silu) {
+    // LDS: per-(thread row) channel sums, [rows][2][Cw]; summed in a fixed order afterwards (no atomics, so
+    // the result is bit-reproducible from call to call)
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    __shared__ float part_sum[GN_THREADS][2];
+    __shared__ float grp_stat[GN_GROUPS][2];
+    const int C = C1 + C2, cpg = C / GN_GROUPS;
+    const int gch = gridDim.z, Gw = GN_GROUPS / gch, Cw = C / gch;
+    const int v0 = (blockIdx.z * Cw) >> 3, nvec = Cw >> 3;
+    const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+    const int tid = threadIdx.x;
+
+    const int cols = nvec < GN_THREADS ? nvec : GN_THREADS;
+    const int rows = GN_THREADS / cols;
+    const int tcol = tid % cols, trow = tid / cols;
+    const int64_t p_begin = (int64_t)slab * P;
+    const int64_t p_end = (p_begin + P < hw) ? p_begin + P : hw;
+    if (trow < rows) {
+        float* mine = sh + (size_t)trow * 2 * Cw;
+        for (int v = tcol; v < nvec; v += cols) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+            // four pixel rows per trip: the four 16-byte loads are in flight together
+            int64_t pix = p_begin + trow;
+            for (; pix + 3 * rows < p_end; pix += 4 * rows) {
+                uint4 raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix + u * rows, v0 + v);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    elem_unpack8<DT>(raw[u], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+                }
+            }
+            for (; pix < p_end; pix += rows) {
+                const uint4 raw = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix, v0 + v);
+                float f[8];
+                elem_unpack8<DT>(raw, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mine[v * 8 + j] = s[j];
+                mine[Cw + v * 8 + j] = ss[j];
+            }
+        }
+    }
+    __syncthreads();
+    // per-group totals: GN_THREADS/Gw threads per group each sum a fixed interleaved subset, then one thread adds them
+    const int nparts = GN_THREADS / Gw;
+    {
+        const int g = tid % Gw, part = tid / Gw;
+        float S = 0.f, SS = 0.f;
+        for (int e = part; e < rows * cpg; e += nparts) {
+            const int r = e / cpg, j = e - r * cpg;
+            const float* rowp = sh + (size_t)r * 2 * Cw;
+            S += rowp[g * cpg + j];
+            SS += rowp[Cw + g * cpg + j];
+        }
+        part_sum[part * Gw + g][0] = S;
+        part_sum[part * Gw + g][1] = SS;
+    }
+    __syncthreads();
+    if (tid < Gw) {
+        float S = 0.f, SS = 0.f;
+        for (int part = 0; part < nparts; ++part) { S += part_sum[part * Gw + tid][0]; SS += part_sum[part * Gw + tid][1]; }
+        const float n = (float)((p_end - p_begin) * cpg);
+        const float mean = S / n;
+        float m2 = SS - S * mean;
+        if (m2 < 0.f) m2 = 0.f;
+        if (FUSED) {
+            grp_stat[tid][0] = mean;
+            grp_stat[tid][1] = rsqrtf(m2 / n + eps);
+        } else {
+            float* o = partial + (((int64_t)b * nslab + slab) * GN_GROUPS + blockIdx.z * Gw + tid) * 3;
+            o[0] = n; o[1] = mean; o[2] = m2;
+        }
+    }
+    if (FUSED) {
+        __syncthreads();      // grp_stat visible; the per-row sums in `sh` are dead and become the scale/shift tables
+        gn_apply_stream<DT>(x1, x2, C1, C2, gamma, beta, &grp_stat[0][0], out, hw, p_begin, p_end, b, blockIdx.z * Cw, Cw,
+                            cpg, silu, sh);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned short* __restrict__ x1,
+                                                              const unsigned short* __restrict__ x2, int C1, int C2,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ partial, float eps,
+                                                              unsigned short* __restrict__ out, int64_t hw, int64_t P,
+                                                              int silu) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // scale[Cw], shift[Cw]
+    __shared__ float sub_stat[GN_THREADS][3];
+    __shared__ float grp_stat[GN_GROUPS][2];
+    const int C = C1 + C2, cpg = C / GN_GROUPS;
+    const int gch = gridDim.z, Gw = GN_GROUPS / gch, Cw = C / gch;
+    const int c0 = blockIdx.z * Cw;
+    const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+    const int tid = threadIdx.x;
+    // Every block merges the slab partials of its groups itself (fixed order: up to 8 interleaved chains per
+    // group, then the chain results in order), which replaces a separate single-block finalize launch.
+    const int nsub = GN_THREADS / Gw < 8 ? GN_THREADS / Gw : 8;
+    {
+        const int g = tid % Gw, sub = tid / Gw;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        if (sub < nsub) {
+            // four slabs per trip: their 12 loads are in flight together, then merged in slab order
+            for (int base = sub; base < nslab; base += 4 * nsub) {
+                float pn[4], pm[4], p2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sl = base + u * nsub;
+                    const bool ok = sl < nslab;
+                    const float* pp = partial + (((int64_t)b * nslab + (ok ? sl : 0)) * GN_GROUPS + blockIdx.z * Gw + g) * 3;
+                    pn[u] = ok ? pp[0] : 0.f; pm[u] = pp[1]; p2[u] = pp[2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gn_merge(n, mean, m2, pn[u], pm[u], p2[u]);
+            }
+            sub_stat[sub * Gw + g][0] = n; sub_stat[sub * Gw + g][1] = mean; sub_stat[sub * Gw + g][2] = m2;
+        }
+    }
+    __syncthreads();
+    if (tid < Gw) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int sub = 0; sub < nsub; ++sub)
+            gn_merge(n, mean, m2, sub_stat[sub * Gw + tid][0], sub_stat[sub * Gw + tid][1], sub_stat[sub * Gw + tid][2]);
+        grp_stat[tid][0] = mean;
+        grp_stat[tid][1] = rsqrtf(m2 / n + eps);
+    }
+    __syncthreads();
+    gn_apply_stream<DT>(x1, x2, C1, C2, gamma, beta, &grp_stat[0][0], out, hw, p_begin_of(slab, P), p_end_of(slab, P, hw),
+                        b, c0, Cw, cpg, silu, sh);
 }
 
 // LayerNorm: one wave per row, row held in registers (C <= 2048), exact two-pass statistics.
@@ -284,21 +336,35 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     if (C1 % 8 != 0 || C2 % 8 != 0 || C % GN_GROUPS != 0) return SDMI_ERR_ALIGNMENT;
     if (2 * C * (int)sizeof(float) > 64 * 1024) return SDMI_ERR_BAD_ARG;
     if (workspace == nullptr || workspace_bytes < sdmi_groupnorm_workspace_bytes(nb, hw)) return SDMI_ERR_WORKSPACE;
-    const int64_t P = gn_slab_pixels(hw);
+    // Small images (<= 1024 pixels): one slab per image and one fused launch; else P-pixel slabs and two launches.
+    const bool fused = hw <= 1024;
+    const int64_t P = fused ? hw : gn_slab_pixels(hw);
     const int nslab = (int)((hw + P - 1) / P);
+    // channel chunks (whole groups, 16-byte aligned) until the grid can fill the chip
+    int gch = 1;
+    while (gch < GN_GROUPS && (int64_t)nslab * nb * gch < 512 && (C / (gch * 2)) % 8 == 0) gch *= 2;
+    const int Cw = C / gch;
     float* partial = reinterpret_cast<float*>(workspace);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)nslab, (unsigned)nb);
-    const size_t lds = 2 * (size_t)C * sizeof(float);
-    const int nvec_h = C / 8;
+    const dim3 grid((unsigned)nslab, (unsigned)nb, (unsigned)gch);
+    const size_t lds = 2 * (size_t)Cw * sizeof(float);
+    const int nvec_h = Cw / 8;
     const int rows_h = GN_THREADS / (nvec_h < GN_THREADS ? nvec_h : GN_THREADS);
     const unsigned short* u1 = reinterpret_cast<const unsigned short*>(x1);
     const unsigned short* u2 = reinterpret_cast<const unsigned short*>(x2);
     unsigned short* uo = reinterpret_cast<unsigned short*>(out);
+    if (fused) {
+        if (dtype == SDMI_DTYPE_F16)
+            hipLaunchKernelGGL((gn_stats_kernel<1, true>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
+        else
+            hipLaunchKernelGGL((gn_stats_kernel<0, true>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
+        SDMI_CHECK_LAUNCH();
+        return SDMI_OK;
+    }
     if (dtype == SDMI_DTYPE_F16)
-        hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial);
+        hipLaunchKernelGGL((gn_stats_kernel<1, false>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
     else
-        hipLaunchKernelGGL(gn_stats_kernel<0>, grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial);
+        hipLaunchKernelGGL((gn_stats_kernel<0, false>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
     SDMI_CHECK_LAUNCH();
     if (dtype == SDMI_DTYPE_F16)
         hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
