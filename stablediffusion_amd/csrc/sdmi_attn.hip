@@ -15,6 +15,10 @@
 // reads for 32 rows at one chunk), V chunk ^= ((row>>1)&1)<<2 (conflict-free transposed reads).
 #include "sdmi_common.h"
 
+#ifndef SDMI_ATTN_OCC
+#define SDMI_ATTN_OCC 2
+#endif
+
 namespace {
 
 constexpr int QB = 128;      // query rows per workgroup
@@ -43,7 +47,7 @@ __device__ __forceinline__ uint4 cvt8(const f32x16& s, int base) {
 }
 
 template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_d64_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) uint4 lds[4 * TILE_CH];   // K0 K1 V0 V1
     uint4* const Ks = lds;
     uint4* const Vs = lds + 2 * TILE_CH;

@@ -250,3 +250,40 @@ def test_unet_h64_batch2_vs_oracle(dev, dt):
     print(f"[parity] sd2 unet h64 batch 2 ({dt}): rel_err vs fp32 oracle {rel_err(y, ref):.3e} "
           f"(format floor = oracle with {dt}-rounded operands vs fp32 oracle: {rel_err(emul, ref):.3e})")
     assert rel_err(y, ref) < TOL[dt]
+
+
+def test_unet_768_v_prediction_vs_oracle(dev):
+    """BASELINE config 3 shape: SD2.1-v 768^2 = 96x96 latent, 9216-token self-attention, v-prediction head
+    (same UNet; parameterization only changes how the sampler reads the output).  One forward, batch 1, fp16
+    operands (the dtype v2-inference-v.yaml ships), against the fp32 oracle on the host cores."""
+    from oracle import model as OM
+    from stablediffusion_amd.unet import UNetModel
+    m, sd = build(UNetModel, policy(synth.SD2_UNET, "fp16"), "unet.", dev)
+    x = synth.synth_input("h96_x", (1, 4, 96, 96))
+    ctx = synth.synth_input("h96_ctx", (1, 77, 1024))
+    t = torch.tensor([741])
+    y = m(x.to(dev), t.to(dev), ctx.to(dev))
+    assert y.shape == (1, 4, 96, 96) and bool(torch.isfinite(y).all())
+    with torch.no_grad():
+        ref = OM.unet_forward(sd, synth.SD2_UNET, x, t, ctx)
+    print(f"[parity] sd2 unet h96 (768^2, 9216 tokens) fp16: rel_err vs fp32 oracle {rel_err(y, ref):.3e}")
+    assert rel_err(y, ref) < NORTH_STAR
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_decoder_768_batch_is_per_image(dev, dt):
+    """BASELINE config 4 shape: decode_first_stage standalone at 768^2.  Size-independent property instead of a
+    CPU decode (5.6 TFLOP per image): images of a batch are independent, so decoding 4 latents at once must give
+    what decoding each alone gives (up to the fp32 summation order of the split-K plan, which depends on M)."""
+    from stablediffusion_amd.vae import AutoencoderKL
+    vae, _ = build(AutoencoderKL, dict(ddconfig=synth.SD2_DDCONFIG, embed_dim=4), "vae.", dev)
+    vae.set_compute_dtype(TORCH_DT[dt])
+    z = synth.synth_input("z768", (4, 4, 96, 96)).to(dev)
+    full = vae.decode(z, 1 / 0.18215)
+    assert full.shape == (4, 3, 768, 768) and bool(torch.isfinite(full).all())
+    worst = 0.0
+    for i in (0, 3):
+        one = vae.decode(z[i:i + 1].contiguous(), 1 / 0.18215)
+        worst = max(worst, rel_err(full[i:i + 1], one))
+    print(f"[parity] sd2 decoder 768^2 batch 4 vs per-image ({dt}): rel_err {worst:.3e}")
+    assert worst < TOL[dt]      # rounding noise of the operand format, re-ordered by a different tile plan
