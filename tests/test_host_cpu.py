@@ -264,3 +264,51 @@ def test_dp_gather_world2_gloo():
                            capture_output=True, text=True, timeout=240, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DP_OK" in p.stdout
+
+
+def test_txt2img_surface(tmp_path):
+    """scripts/txt2img.py surface: option names/defaults (txt2img.py:67-243), checkpoint loader semantics
+    (txt2img.py:21-64: non-strict load, upstream key spellings, nothing executed from the file), loud failure
+    off the GPU."""
+    import yaml
+    from tests import synth
+    from stablediffusion_amd import txt2img
+    a = txt2img.parse_args([])
+    assert (a.steps, a.n_iter, a.n_samples, a.scale, a.height, a.width, a.channel, a.factor) == (50, 3, 3, 9.0, 512, 512, 4, 8)
+    assert a.ddim_eta == 0.0 and a.seed == 42 and a.precision == "autocast" and not a.plms and a.device == "cuda"
+    a = txt2img.parse_args(["--plms", "--H", "768", "--W", "768", "--outdir", "x", "--from_file", "p.txt", "--repeat", "2"])
+    assert a.plms and a.height == 768 and a.out_dir == "x" and a.repeat == 2
+    assert list(txt2img.chunk(range(5), 2)) == [(0, 1), (2, 3), (4,)]
+    up = txt2img.DEFAULT_CONFIG["model"]["params"]["unet_config"]["params"]
+    assert up["model_channels"] == 320 and up["context_dim"] == 1024 and up["use_fp16"]
+
+    cfg = {"model": {"target": "ldm.models.diffusion.ddpm.LatentDiffusion", "params": {
+        "linear_start": 0.00085, "linear_end": 0.012, "timesteps": 1000, "scale_factor": 0.18215,
+        "conditioning_key": "crossattn",
+        "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.TINY_UNET)},
+        "first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL",
+                               "params": {"embed_dim": 4, "ddconfig": dict(synth.TINY_DDCONFIG)}},
+        "cond_stage_config": {"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder", "params": {}}}}}
+    path = tmp_path / "tiny.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    assert txt2img.load_config(str(path)) == cfg
+    # a checkpoint in upstream spelling, saved as plain tensors
+    from stablediffusion_amd.util import instantiate_from_config
+    ref_model = instantiate_from_config(cfg["model"])
+    sd = {}
+    for k, v in ref_model.state_dict().items():
+        sd[k.replace(".up_sample.", ".upsample.")] = torch.full_like(v, 0.25) if v.is_floating_point() else v
+    ckpt = tmp_path / "tiny.ckpt"
+    torch.save({"state_dict": sd, "global_step": 7}, ckpt)
+    with pytest.raises(ValueError, match="GPU only"):
+        txt2img.load_model_from_config(cfg, str(ckpt), device="cpu")
+    got, step = txt2img._read_checkpoint(str(ckpt))
+    assert step == 7 and set(got) == set(sd)
+    m = instantiate_from_config(cfg["model"])
+    missing, unexpected = m.load_state_dict(got, strict=False)
+    assert not [k for k in missing if "diffusion_model" in k or "first_stage" in k] and not unexpected
+    assert float(m.model.diffusion_model.out[2].weight.flatten()[0]) == 0.25
+    with pytest.raises(NotImplementedError):
+        txt2img.main(txt2img.parse_args(["--ipex"]))
+    with pytest.raises(NotImplementedError):
+        txt2img.main(txt2img.parse_args(["--dpm"]))
