@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--parameterization", default="eps", choices=["eps", "v"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the UNet step from a captured hipGraph (auto: when batch <= 2, where the step is launch-bound)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the BASELINE configs[1] (batch 1) latency leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,8 +185,9 @@ def main():
     from stablediffusion_amd.ddim import DDIMSampler
     from stablediffusion_amd import ops
     model = build_model(dev, args.parameterization)
-    sampler = DDIMSampler(model)
     B, h = args.batch, args.latent
+    use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and B <= 2)
+    sampler = DDIMSampler(model, hip_graph=use_graph)
     # synthetic inputs of SURVEY.md §8(d): per-rank latents, shared "prompt" embeddings
     from stablediffusion_amd import dp
     x_T = dp.shard_latents(world * B, rank, world, (4, h, h), base_seed=1234).to(dev)   # seeds follow the GLOBAL index
@@ -231,7 +235,7 @@ def main():
                                f"{args.ddim_steps} DDIM steps + CFG (UNet batch {2 * B}), decode + uint8; "
                                f"BASELINE.json configs[{1 if B == 1 else 2}]",
                    "global_batch": world * B, "latent": h, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world}",
-                   "parameterization": args.parameterization},
+                   "parameterization": args.parameterization, "hip_graph": use_graph},
         "unet_step_ms": None,
         "effective_tflops_per_gpu": value / world * flop_per_image / 1e12 if flop_per_image else None,
         "mfma_frac_end_to_end": value / world * flop_per_image / 1e12 / MFMA_PEAK_TFLOPS if flop_per_image else None,
@@ -253,6 +257,38 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     result["decode_ms"] = e0.elapsed_time(e1)
+
+    # BASELINE configs[1]: batch 1 (UNet batch 2), 50 DDIM steps + CFG, one GPU - the latency case.  The step is
+    # launch-bound there, so it is replayed from a hipGraph; eager numbers are printed beside it.
+    if world == 1 and B != 1 and not args.no_batch1:
+        from stablediffusion_amd.graph import GraphedApplyModel
+        x1, c1, uc1 = x_T[:1].contiguous(), c[:1].contiguous(), uc[:1].contiguous()
+        lat = DDIMSampler(model, hip_graph=True)
+
+        def one_image():
+            smp, _ = lat.sample(S=args.ddim_steps, batch_size=1, shape=[4, h, h], conditioning=c1, verbose=False,
+                                unconditional_guidance_scale=args.scale, unconditional_conditioning=uc1, eta=0.0, x_T=x1)
+            return ops.image_to_u8(model.decode_first_stage(smp))
+        one_image()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_image()
+        torch.cuda.synchronize()
+        t_img = time.perf_counter() - t1
+        cin1 = torch.cat([uc1, c1]).contiguous()
+        xin1, ts1 = torch.cat([x1, x1]), torch.full((2,), 501, device=dev, dtype=torch.long)
+        steps_ms = {}
+        for name, fn in (("graph", GraphedApplyModel(model)), ("eager", model.apply_model)):
+            fn(xin1, ts1, cin1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                fn(xin1, ts1, cin1)
+            torch.cuda.synchronize()
+            steps_ms[name] = (time.perf_counter() - t1) / 10 * 1e3
+        result["batch1"] = {"workload": "BASELINE.json configs[1]: batch 1, UNet batch 2 (CFG), hipGraph replay of the UNet step",
+                            "s_per_image": t_img, "images_per_sec": 1.0 / t_img,
+                            "unet_step_ms_graph": steps_ms["graph"], "unet_step_ms_eager": steps_ms["eager"]}
 
     if rank == 0:
         if not args.no_roofline:

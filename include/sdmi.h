@@ -171,6 +171,12 @@ int sdmi_ddim_step(const float* x, const float* model_out, const float* noise, f
                    float sqrt_one_minus_a_t, int32_t v_param, void* stream);
 /* clamp((x + 1) / 2, 0, 1) * 255 -> uint8, NCHW fp32 in, NHWC uint8 out (the image post-processing that
  * follows decode_first_stage in upstream txt2img; absent after scripts/txt2img.py:402). */
+/* out = w0*x0 + w1*x1 + w2*x2 + w3*x3 over n fp32 elements; x1..x3 may be NULL.  The eps combinations of the PLMS
+ * multistep sampler (absent from the reference, named by txt2img.py:96-100 `--plms`; upstream plms.py p_sample_plms)
+ * and the classifier-free-guidance combine (1-s)*e_uc + s*e_c when it is not fused into sdmi_ddim_step. */
+int sdmi_lincomb4(const float* x0, const float* x1, const float* x2, const float* x3, float w0, float w1, float w2,
+                  float w3, float* out, int64_t n, void* stream);
+
 int sdmi_image_to_u8(const float* x, uint8_t* out, int32_t nb, int32_t C, int64_t hw, void* stream);
 
 #ifdef __cplusplus

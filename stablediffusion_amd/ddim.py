@@ -15,9 +15,15 @@ from .schedule import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
 class DDIMSampler(object):
-    def __init__(self, model, schedule="linear", device=None, **kwargs):
+    def __init__(self, model, schedule="linear", device=None, hip_graph=False, **kwargs):
+        """hip_graph=True replays the UNet step from a captured hipGraph (graph.py): worth it when the step is
+        launch-bound (small batch); results are bit-identical to eager launches."""
         super().__init__()
         self.model = model
+        self._apply = model.apply_model
+        if hip_graph:
+            from .graph import GraphedApplyModel
+            self._apply = GraphedApplyModel(model)
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.device = torch.device(device) if device is not None else model.device
@@ -121,7 +127,7 @@ class DDIMSampler(object):
             n_in = 2 * b if cfg else b
             ts = torch.full((n_in,), int(step), device=device, dtype=torch.long)
             x_in = torch.cat([img, img]) if cfg else img
-            model_out = self.model.apply_model(x_in, ts, c_in)           # ONE UNet forward, batch 2B with CFG
+            model_out = self._apply(x_in, ts, c_in)           # ONE UNet forward, batch 2B with CFG
             sigma = float(self.ddim_sigmas[index])
             noise = torch.randn_like(img) * temperature if sigma > 0 else None
             img, pred_x0 = ops.ddim_step(

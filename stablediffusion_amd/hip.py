@@ -47,6 +47,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "sdmi_status_str": (C.c_char_p, [C.c_int]),
     "sdmi_abi_version": (C.c_int, []),
+    "sdmi_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "sdmi_gemm_tile_m": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32]),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),

@@ -157,7 +157,7 @@ def _plan_gemm(m, n_w, k, tile_n=_BN):
             if blocks < _CUS:
                 cost *= 0.8 + 0.2 * blocks / _CUS       # a partly idle chip clocks higher and contends less
             if s > 1:
-                cost += (2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 3.0   # slab write+read (mostly L2/MALL) + launch
+                cost += (2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 7.0   # slab write+read (mostly L2/MALL) + the extra launch
             if best_cost is None or cost < best_cost * 0.97:
                 best, best_cost = (tile_m, s, 3), cost
     return best
@@ -443,6 +443,22 @@ def ddim_step(x, model_out, a_t, a_prev, sigma_t, sqrt_one_minus_a_t, guidance_s
                                        guidance_scale, a_t, a_prev, sigma_t, sqrt_one_minus_a_t, 1 if v_param else 0,
                                        _stream()), "sdmi_ddim_step")
     return x_prev, pred
+
+
+def lincomb(terms):
+    """sum_i w_i * x_i over up to four fp32 tensors of one shape: terms = [(w, x), ...]."""
+    if not 1 <= len(terms) <= 4:
+        raise hip.SdmiError("lincomb takes one to four terms")
+    xs = [t[1] for t in terms]
+    for x in xs:
+        _require(x, torch.float32, "x")
+        if x.shape != xs[0].shape:
+            raise hip.SdmiError("lincomb: shapes differ")
+    out = torch.empty_like(xs[0])
+    ptr = [_p(x) for x in xs] + [None] * (4 - len(xs))
+    w = [float(t[0]) for t in terms] + [0.0] * (4 - len(terms))
+    hip.check(hip.lib().sdmi_lincomb4(*ptr, *w, _p(out), out.numel(), _stream()), "sdmi_lincomb4")
+    return out
 
 
 def image_to_u8(x):

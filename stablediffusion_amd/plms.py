@@ -1,9 +1,8 @@
 """PLMSSampler on the HIP path.  The reference only parses ``--plms``
 (scripts/txt2img.py:96-100) and has no plms.py; this is upstream's pseudo linear multistep sampler
 restated: 4th-order Adams-Bashforth on eps with a 2-evaluation first step, eta = 0,
-eps-parameterisation, around the same ``apply_model`` call as DDIM.  No new kernels: the eps
-history is combined with torch elementwise ops on [B,4,h,w] latents (negligible) and the x_prev
-update reuses sdmi_ddim_step.
+eps-parameterisation, around the same ``apply_model`` call as DDIM.  The guidance combine and the
+multistep eps combination run in sdmi_lincomb4, the x_prev update reuses sdmi_ddim_step.
 """
 import numpy as np
 import torch
@@ -37,11 +36,11 @@ class PLMSSampler(DDIMSampler):
         def eps_at(x, step):
             n_in = 2 * b if cfg else b
             ts = torch.full((n_in,), int(step), device=device, dtype=torch.long)
-            out = self.model.apply_model(torch.cat([x, x]) if cfg else x, ts, c_in).float()
+            out = self._apply(torch.cat([x, x]) if cfg else x, ts, c_in).float()
             if cfg:
-                e_uc, e_c = out.chunk(2)
-                return e_uc + scale * (e_c - e_uc)
-            return out
+                e_uc, e_c = out[:b].contiguous(), out[b:].contiguous()
+                return ops.lincomb([(1.0 - scale, e_uc), (scale, e_c)])
+            return out.contiguous()
 
         def x_prev_of(x, e, index):
             return ops.ddim_step(x, e.contiguous(), float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index]),
@@ -54,13 +53,13 @@ class PLMSSampler(DDIMSampler):
             e_t = eps_at(img, step)
             if len(old_eps) == 0:
                 x_p, _ = x_prev_of(img, e_t, index)
-                e_prime = (e_t + eps_at(x_p, step_next)) / 2
+                e_prime = ops.lincomb([(0.5, e_t), (0.5, eps_at(x_p, step_next))])
             elif len(old_eps) == 1:
-                e_prime = (3 * e_t - old_eps[-1]) / 2
+                e_prime = ops.lincomb([(1.5, e_t), (-0.5, old_eps[-1])])
             elif len(old_eps) == 2:
-                e_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+                e_prime = ops.lincomb([(23 / 12, e_t), (-16 / 12, old_eps[-1]), (5 / 12, old_eps[-2])])
             else:
-                e_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+                e_prime = ops.lincomb([(55 / 24, e_t), (-59 / 24, old_eps[-1]), (37 / 24, old_eps[-2]), (-9 / 24, old_eps[-3])])
             img, pred_x0 = x_prev_of(img, e_prime, index)
             old_eps = (old_eps + [e_t])[-3:]
             if callback:

@@ -317,3 +317,21 @@ def test_txt2img_main_end_to_end(dev, tmp_path):
     assert grids[0].shape == (2, 32, 32, 3) and grids[0].dtype == torch.uint8
     assert torch.equal(grids[0], grids[1])          # same seed, same images (the HIP path is deterministic)
     assert not torch.equal(grids[0], grids[2])      # another seed (and the PLMS loop): other images
+
+
+def test_hip_graph_replay_is_bit_identical(dev):
+    """DDIMSampler(hip_graph=True) replays the captured UNet step: same latents, bit for bit, as eager launches,
+    across steps (different timesteps / inputs through the static buffers) and across two sample() calls."""
+    from stablediffusion_amd.ddim import DDIMSampler
+    model, _ = _latent_diffusion(dev, policy(synth.TINY_UNET, "bf16"), synth.TINY_DDCONFIG)
+    x_T = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    c = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(6)).to(dev)
+    uc = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(7)).to(dev)
+    kw = dict(S=6, batch_size=2, shape=[4, 16, 16], conditioning=c, verbose=False, unconditional_guidance_scale=4.0,
+              unconditional_conditioning=uc, eta=0.0)
+    eager, _ = DDIMSampler(model).sample(x_T=x_T, **kw)
+    g = DDIMSampler(model, hip_graph=True)
+    a, _ = g.sample(x_T=x_T, **kw)
+    b, _ = g.sample(x_T=x_T * 0.5, **kw)
+    b_eager, _ = DDIMSampler(model).sample(x_T=x_T * 0.5, **kw)
+    assert torch.equal(a, eager) and torch.equal(b, b_eager) and not torch.equal(a, b)
