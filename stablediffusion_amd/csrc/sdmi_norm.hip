@@ -255,25 +255,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
                         b, c0, Cw, cpg, silu, sh);
 }
 
-// LayerNorm: one wave per row, row held in registers (C <= 2048), exact two-pass statistics.
-constexpr int LN_MAXV = 4;   // 64 lanes x 4 vectors x 8 = 2048 channels
+// LayerNorm: LPR lanes per row (a power of two <= 64 chosen by the host so that C/8 vectors split evenly, e.g.
+// C = 320 -> 8 lanes x 5 vectors, and a wave covers 64/LPR rows), row held in registers, exact two-pass statistics
+// with the reductions inside the LPR-lane group.  Consecutive lanes of a group read consecutive 16-byte vectors.
+constexpr int LN_MAXV = 5;   // vectors per lane
 
 template <int DT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         unsigned short* __restrict__ out, int64_t rows, int C,
-                                                        float eps) {
+                                                        float eps, int lpr) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nvec = C >> 3;
+    const int rpw = 64 / lpr;                        // rows per wave
+    const int sub = lane / lpr, li = lane - sub * lpr;
     const float inv_c = 1.0f / (float)C;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
-        const unsigned short* xr = x + row * C;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * rpw; row0 < rows; row0 += (int64_t)gridDim.x * 4 * rpw) {
+        const int64_t row = row0 + sub;
+        const bool rok = row < rows;
+        const unsigned short* xr = x + (rok ? row : 0) * C;
         float f[LN_MAXV][8];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            const int v = lane + 64 * i;
+            const int v = li + lpr * i;
             if (v < nvec) {
                 const uint4 raw = *reinterpret_cast<const uint4*>(xr + v * 8);
                 elem_unpack8<DT>(raw, f[i]);
@@ -281,25 +287,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
                 for (int j = 0; j < 8; ++j) s += f[i][j];
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float mean = s * inv_c;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            const int v = lane + 64 * i;
+            const int v = li + lpr * i;
             if (v < nvec) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; q += d * d; }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        for (int o = lpr >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
         const float rstd = rsqrtf(q * inv_c + eps);
+        if (!rok) continue;
         unsigned short* orow = out + row * C;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            const int v = lane + 64 * i;
+            const int v = li + lpr * i;
             if (v < nvec) {
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
                 const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
@@ -380,16 +385,21 @@ extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* be
     if (x == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (rows <= 0 || C <= 0) return SDMI_ERR_BAD_ARG;
     if (C % 8 != 0 || C > 64 * LN_MAXV * 8) return SDMI_ERR_ALIGNMENT;
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
+    // lanes per row: the smallest power of two that holds the row in LN_MAXV vectors per lane
+    const int nvec = C / 8;
+    int lpr = 1;
+    while (lpr < 64 && nvec > lpr * LN_MAXV) lpr *= 2;
+    const int rpw = 64 / lpr;
+    int64_t blocks = (rows + 4 * rpw - 1) / (4 * rpw);
+    if (blocks > 16384) blocks = 16384;
     if (dtype == SDMI_DTYPE_F16)
         hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
-                           rows, C, eps);
+                           rows, C, eps, lpr);
     else
         hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
-                           rows, C, eps);
+                           rows, C, eps, lpr);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }
