@@ -10,9 +10,11 @@
 //                                                  converted to bf16 in place (no LDS round trip)
 // The k-order of an accumulator-as-operand is permuted: element j of lane half h of k-step s is key
 // 16s + 8(j>>2) + 4h + (j&3); the V^T fragment is read in exactly that order.
-// K and V tiles are double-buffered in LDS (32 KiB), staged through registers with the global loads of
-// tile t+1 issued before the MFMAs of tile t.  Swizzles: K chunk ^= (row>>1)&7 (conflict-free b128
-// reads for 32 rows at one chunk), V chunk ^= ((row>>1)&1)<<2 (conflict-free transposed reads).
+// K and V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into a
+// 3-stage ring (48 KiB): tile t+2 is issued before the MFMAs of tile t and retired with a counted vmcnt, so one
+// younger tile stays in flight across the barrier.  Swizzles (applied to the SOURCE address, the DMA writes
+// linearly): K chunk ^= (row>>1)&7 (conflict-free b128 reads for 32 rows at one chunk), V chunk ^= ((row>>1)&1)<<2
+// (conflict-free transposed reads).  Keys past Nk are fetched from a zero constant.
 #include "sdmi_common.h"
 
 #ifndef SDMI_ATTN_OCC
@@ -25,6 +27,9 @@ constexpr int QB = 128;      // query rows per workgroup
 constexpr int KB = 64;       // keys per tile
 constexpr int D = 64;
 constexpr int TILE_CH = KB * (D / 8);   // 16-byte chunks per K or V tile (512)
+constexpr int NST = 3;                  // ring stages
+
+__device__ const uint4 attn_zero16 = {0u, 0u, 0u, 0u};
 
 struct AttnArgs {
     const unsigned short* q; const unsigned short* k; const unsigned short* v; unsigned short* out;
@@ -32,11 +37,6 @@ struct AttnArgs {
     int64_t ldq, ldk, ldv, ldo;
     float c;   // scale * log2(e)
 };
-
-__device__ __forceinline__ uint4 zero_unless(uint4 v, bool ok) {
-    v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-    return v;
-}
 
 template <int DT>
 __device__ __forceinline__ uint4 cvt8(const f32x16& s, int base) {
@@ -48,9 +48,7 @@ __device__ __forceinline__ uint4 cvt8(const f32x16& s, int base) {
 
 template <int DT>
 __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) uint4 lds[4 * TILE_CH];   // K0 K1 V0 V1
-    uint4* const Ks = lds;
-    uint4* const Vs = lds + 2 * TILE_CH;
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * NST * TILE_CH];   // stage s: K tile at 2s, V tile at 2s+1
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lr = lane & 31, hf = lane >> 5;
@@ -75,44 +73,45 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
 
-    // staging: thread owns chunk (row = id>>3, c = id&7) for id = tid and tid+256
-    const int sc = tid & 7, sr = tid >> 3;   // rows sr and sr+32
-    // Named staging registers + macros (arrays captured by lambdas end up in scratch).  Rows past Nk are
-    // loaded from row 0 and zeroed by value when written to LDS.
-    uint4 rk0, rk1, rv0, rv1;
-    bool ok0 = false, ok1 = false;
-#define ATTN_LOAD_TILE(T)                                                                      \
+    // ---- staging: wave w issues, per tile, K rows {8w..8w+7, 32+8w..} and the same V rows: 4 DMA instructions ----
+    // lane l of an instruction owns physical chunk l&7 of row R = 32*i + 8*w + (l>>3) and fetches the logical chunk
+    // the read side expects there (K: ^ (R>>1)&7, V: ^ ((R>>1)&1)<<2).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds;
+    const unsigned d_wave = lds_base + wave_u * 1024;
+    const int srow = 8 * wave_u + (lane >> 3);           // rows srow and srow + 32
+    const int spc = lane & 7;
+    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(&attn_zero16);
+    // ((srow+32)>>1)&7 == (srow>>1)&7, so both rows of a lane use the same logical chunk
+    const int kch = spc ^ ((srow >> 1) & 7), vch = spc ^ (((srow >> 1) & 1) << 2);
+    const unsigned short* kp0 = Kp + (int64_t)srow * p.ldk + kch * 8;
+    const unsigned short* kp1 = kp0 + 32 * p.ldk;
+    const unsigned short* vp0 = Vp + (int64_t)srow * p.ldv + vch * 8;
+    const unsigned short* vp1 = vp0 + 32 * p.ldv;
+    const int64_t kstep = (int64_t)KB * p.ldk, vstep = (int64_t)KB * p.ldv;
+    // Issue tile T into ring stage ST; pointers advance by one tile.  Rows past Nk (last tile only) read zeros.
+#define ATTN_STAGE_TILE(T, ST)                                                                 \
     do {                                                                                       \
-        const int key0_ = (T) * KB + sr, key1_ = key0_ + 32;                                   \
-        ok0 = key0_ < p.Nk; ok1 = key1_ < p.Nk;                                                \
-        const int64_t r0_ = ok0 ? key0_ : 0, r1_ = ok1 ? key1_ : 0;                            \
-        rk0 = *reinterpret_cast<const uint4*>(Kp + r0_ * p.ldk + sc * 8);                      \
-        rk1 = *reinterpret_cast<const uint4*>(Kp + r1_ * p.ldk + sc * 8);                      \
-        rv0 = *reinterpret_cast<const uint4*>(Vp + r0_ * p.ldv + sc * 8);                      \
-        rv1 = *reinterpret_cast<const uint4*>(Vp + r1_ * p.ldv + sc * 8);                      \
-    } while (0)
-    const int k_idx0 = sr * 8 + (sc ^ ((sr >> 1) & 7));            // row sr
-    const int k_idx1 = (sr + 32) * 8 + (sc ^ ((sr >> 1) & 7));     // row sr+32: ((sr+32)>>1)&7 == (sr>>1)&7
-    const int v_idx0 = sr * 8 + (sc ^ (((sr >> 1) & 1) << 2));
-    const int v_idx1 = (sr + 32) * 8 + (sc ^ (((sr >> 1) & 1) << 2));
-#define ATTN_STORE_TILE(BUF, FULL)                                                             \
-    do {                                                                                       \
-        if (FULL) {   /* uniform: every key of the tile exists, nothing to zero */             \
-            Ks[(BUF) * TILE_CH + k_idx0] = rk0;                                                \
-            Ks[(BUF) * TILE_CH + k_idx1] = rk1;                                                \
-            Vs[(BUF) * TILE_CH + v_idx0] = rv0;                                                \
-            Vs[(BUF) * TILE_CH + v_idx1] = rv1;                                                \
+        const unsigned d0_ = d_wave + (ST) * (2 * TILE_CH * 16);                               \
+        if (((T) + 1) * KB <= p.Nk) {                                                          \
+            glds_v2<0, 4096>(d0_, kp0, kp1);                                                   \
+            glds_v2<TILE_CH * 16, 4096>(d0_, vp0, vp1);                                        \
         } else {                                                                               \
-            Ks[(BUF) * TILE_CH + k_idx0] = zero_unless(rk0, ok0);                              \
-            Ks[(BUF) * TILE_CH + k_idx1] = zero_unless(rk1, ok1);                              \
-            Vs[(BUF) * TILE_CH + v_idx0] = zero_unless(rv0, ok0);                              \
-            Vs[(BUF) * TILE_CH + v_idx1] = zero_unless(rv1, ok1);                              \
+            const bool ok0_ = (T) * KB + srow < p.Nk, ok1_ = (T) * KB + srow + 32 < p.Nk;      \
+            glds_v2<0, 4096>(d0_, ok0_ ? kp0 : zsrc, ok1_ ? kp1 : zsrc);                       \
+            glds_v2<TILE_CH * 16, 4096>(d0_, ok0_ ? vp0 : zsrc, ok1_ ? vp1 : zsrc);            \
         }                                                                                      \
+        kp0 += kstep; kp1 += kstep; vp0 += vstep; vp1 += vstep;                                \
     } while (0)
 
     const int ntiles = (p.Nk + KB - 1) / KB;
-    ATTN_LOAD_TILE(0);
-    ATTN_STORE_TILE(0, KB <= p.Nk);
+    ATTN_STAGE_TILE(0, 0);
+    if (ntiles > 1) {
+        ATTN_STAGE_TILE(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tile 0 landed (this wave's share); tile 1 may fly
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     // transposed-read lane geometry (ds_read_b64_tr_b16, per 16-lane group):
@@ -131,11 +130,12 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
         v_lane[db] = row * 128 + (chunk << 4) + ((tp & 1) << 3);
     }
 
+    int cur = 0, nxt = 2;          // ring stage of tile t / of tile t+2
     for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntiles) ATTN_LOAD_TILE(t + 1);
-        const uint4* Kb = Ks + cur * TILE_CH;
-        const unsigned char* Vb = reinterpret_cast<const unsigned char*>(Vs + cur * TILE_CH);
+        const bool issued = t + 2 < ntiles;
+        if (issued) ATTN_STAGE_TILE(t + 2, nxt);      // into the stage tile t-1 vacated (everyone passed its barrier)
+        const uint4* Kb = lds + cur * (2 * TILE_CH);
+        const unsigned char* Vb = reinterpret_cast<const unsigned char*>(lds + cur * (2 * TILE_CH) + TILE_CH);
 
         // ---- S^T = K Q^T : two 32-key blocks ----
         f32x16 s0, s1;
@@ -213,8 +213,11 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
                 }
             }
         }
-        if (t + 1 < ntiles) ATTN_STORE_TILE(cur ^ 1, (t + 2) * KB <= p.Nk);
+        if (issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile t+1 landed, tile t+2 may still fly
+        else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        cur = cur == NST - 1 ? 0 : cur + 1;
+        nxt = nxt == NST - 1 ? 0 : nxt + 1;
     }
 
     // ---- normalise and store: o_db[r] = O[q = lr][d = db*32 + (r&3) + 8*(r>>2) + 4*hf] ----

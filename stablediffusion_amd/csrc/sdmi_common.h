@@ -119,3 +119,59 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+
+// ---- LDS-DMA issue (global_load_lds_dwordx4, 1 KiB per wave-instruction) ----
+// Issued through inline asm on purpose: with the builtin, hipcc orders every later ds_read behind the DMA
+// (s_waitcnt vmcnt(0) ahead of the MFMAs), which serialises load and compute.  The asm form is invisible to its
+// wait-count pass; the ring is retired by explicit counted s_waitcnt vmcnt(N).  M0 carries the LDS destination:
+// it is saved and restored inside each statement (cdna_hip_programming.md §5.7).  d0 = LDS byte address of this
+// wave's slot in instruction 0 of the stage; instruction i lands O0 + STEP*i bytes further.
+// "_s": scalar 64-bit base + one 32-bit byte offset per lane;  "_v": a 64-bit pointer per lane.
+#define SDMI_M0_SAVE "s_mov_b32 %[keep], m0\n\t"
+#define SDMI_M0_REST "s_mov_b32 m0, %[keep]"
+#define SDMI_LD_S(N) "s_add_u32 m0, %[d0], %[o" #N "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #N "], %[sb]\n\t"
+#define SDMI_LD_V(N) "s_add_u32 m0, %[d0], %[o" #N "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #N "], off\n\t"
+
+template <int O0, int STEP = 8192>
+__device__ __forceinline__ void glds_s2(unsigned d0, const void* sb, unsigned v0, unsigned v1) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_LD_S(1) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [v1] "v"(v1), [o0] "n"(O0), [o1] "n"(O0 + STEP)
+                 : "memory", "scc");
+}
+template <int O0, int STEP = 8192>
+__device__ __forceinline__ void glds_s3(unsigned d0, const void* sb, unsigned v0, unsigned v1, unsigned v2) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_LD_S(1) SDMI_LD_S(2) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [o0] "n"(O0),
+                   [o1] "n"(O0 + STEP), [o2] "n"(O0 + 2 * STEP)
+                 : "memory", "scc");
+}
+template <int O0, int STEP = 8192>
+__device__ __forceinline__ void glds_s4(unsigned d0, const void* sb, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_LD_S(1) SDMI_LD_S(2) SDMI_LD_S(3) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [o0] "n"(O0),
+                   [o1] "n"(O0 + STEP), [o2] "n"(O0 + 2 * STEP), [o3] "n"(O0 + 3 * STEP)
+                 : "memory", "scc");
+}
+template <int O0, int STEP = 8192>
+__device__ __forceinline__ void glds_v2(unsigned d0, const void* v0, const void* v1) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_V(0) SDMI_LD_V(1) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [v0] "v"(v0), [v1] "v"(v1), [o0] "n"(O0), [o1] "n"(O0 + STEP)
+                 : "memory", "scc");
+}
+template <int O0, int STEP = 8192>
+__device__ __forceinline__ void glds_v4(unsigned d0, const void* v0, const void* v1, const void* v2, const void* v3) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_V(0) SDMI_LD_V(1) SDMI_LD_V(2) SDMI_LD_V(3) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [o0] "n"(O0),
+                   [o1] "n"(O0 + STEP), [o2] "n"(O0 + 2 * STEP), [o3] "n"(O0 + 3 * STEP)
+                 : "memory", "scc");
+}
