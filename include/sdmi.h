@@ -93,6 +93,7 @@ typedef struct sdmi_gemm_args {
     float alpha;
     int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it */
     int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 */
+    int32_t res_f32;                    /* 1: `res` is fp32 (only with an fp32 out_kind) - the fp32 mode of the path */
     int32_t stages;                     /* LDS ring depth: 0 | 3 = three stages; 2 (128-row tile only) = two stages,
                                            two blocks per CU - for short K */
 } sdmi_gemm_args;
@@ -176,6 +177,28 @@ int sdmi_ddim_step(const float* x, const float* model_out, const float* noise, f
  * and the classifier-free-guidance combine (1-s)*e_uc + s*e_c when it is not fused into sdmi_ddim_step. */
 int sdmi_lincomb4(const float* x0, const float* x1, const float* x2, const float* x3, float w0, float w1, float w2,
                   float w3, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 mode (the reference's float32 dtype policy, openai_model.py:602-603 with use_fp16 = use_bf16 = False): fp32
+ * channels-last activations; contractions run on sdmi_gemm through the 3 x bf16 split below; the rest is plain fp32.
+ * Built for the "<= 1e-5 in fp32 mode" parity gate, not for speed.
+ *   sdmi_f32_split3: x = [x1 | x2] fp32 [rows, C1 + C2] -> bf16 [rows][6][Cp] planes (x0 x0 x1 x0 x1 x2) with
+ *       x = x0 + x1 + x2 exactly; the matching weight planes are (w0 w1 w0 w2 w1 w0), so a GEMM / conv over 6*Cp
+ *       input channels accumulates the six piece products of weight <= 2 = the fp32 product.  Cp % 8 == 0.
+ *   sdmi_f32_groupnorm / _layernorm / _attention_d64 / _nchw_to_nhwc / _timestep_embedding: fp32 counterparts of
+ *       the 16-bit entry points above (same reference call sites), two-pass statistics, full-precision exp / erf.
+ * ---------------------------------------------------------------------------------------- */
+int sdmi_f32_split3(const float* x1, const float* x2, int32_t C1, int32_t C2, int64_t rows, void* out, int32_t Cp,
+                    void* stream);
+int sdmi_f32_groupnorm(const float* x1, const float* x2, int32_t C1, int32_t C2, const float* gamma, const float* beta,
+                       float* out, int32_t nb, int64_t hw, float eps, int32_t silu, void* stream);
+int sdmi_f32_layernorm(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int32_t C,
+                       float eps, void* stream);
+int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
+                           int32_t Nq, int32_t Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                           void* stream);
+int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, void* stream);
+int sdmi_f32_timestep_embedding(const int64_t* t, float* out, int32_t nb, int32_t dim, float max_period, void* stream);
 
 int sdmi_image_to_u8(const float* x, uint8_t* out, int32_t nb, int32_t C, int64_t hw, void* stream);
 

@@ -118,6 +118,9 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float r = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(r, x);
 }
+// full-precision forms for fp32 outputs (the fp32 mode of the path)
+__device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf_precise(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
 // ---- LDS-DMA issue (global_load_lds_dwordx4, 1 KiB per wave-instruction) ----

@@ -1,0 +1,246 @@
+// sdmi_f32: the fp32 mode of the path (use_fp16 = use_bf16 = False, the reference's float32 dtype policy,
+// openai_model.py:602-603) - built for the parity gate "per-step eps/v <= 1e-5 in fp32 mode", not for speed.
+//
+// Contractions still run on the bf16 MFMA kernels of sdmi_gemm.hip: every fp32 operand is split into three bf16
+// pieces  x = x0 + x1 + x2  (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 = 24 mantissa bits, an
+// exact decomposition of an fp32 value up to its last bit) and the product keeps the six piece pairs of weight
+// i + j <= 2:   x*w ~= x0w0 + x0w1 + x1w0 + x0w2 + x1w1 + x2w0   (dropped terms are below 2^-24 relative).
+// The six pairs are laid out along K - activation planes [x0 x0 x1 x0 x1 x2], weight planes [w0 w1 w0 w2 w1 w0] - so
+// ONE fp32-accumulating bf16 GEMM / implicit-GEMM conv of 6x the K extent computes the fp32 product.  Everything
+// else (norms, softmax, attention with head dim 64, activations) is plain fp32 arithmetic in the kernels below;
+// activations are stored as fp32, channels-last.
+#include "sdmi_common.h"
+
+namespace {
+
+__device__ __forceinline__ void split3(float x, unsigned short& a0, unsigned short& a1, unsigned short& a2) {
+    a0 = f32_to_bf16_bits(x);
+    const float r1 = x - bf16_bits_to_f32(a0);
+    a1 = f32_to_bf16_bits(r1);
+    const float r2 = r1 - bf16_bits_to_f32(a1);
+    a2 = f32_to_bf16_bits(r2);
+}
+
+// x = [x1 | x2] (fp32 rows of C1 + C2 channels) -> out bf16 [rows][6][Cp], planes x0 x0 x1 x0 x1 x2, channels >= C zero
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1,
+                                                     int C2, int64_t rows, unsigned short* __restrict__ out, int Cp) {
+    const int64_t total = rows * Cp;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / Cp;
+        const int c = (int)(idx - r * Cp);
+        float v = 0.f;
+        if (c < C1) v = x1[r * C1 + c];
+        else if (c < C1 + C2) v = x2[r * C2 + (c - C1)];
+        unsigned short a0, a1, a2;
+        split3(v, a0, a1, a2);
+        unsigned short* o = out + r * 6 * Cp + c;
+        o[0] = a0; o[Cp] = a0; o[2 * Cp] = a1; o[3 * Cp] = a0; o[4 * Cp] = a1; o[5 * Cp] = a2;
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// GroupNorm(32)(+SiLU) on fp32 NHWC, input possibly the concat of two tensors: one block per (image, group),
+// exact two-pass statistics.
+__global__ __launch_bounds__(256) void gn_f32_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C1,
+                                                     int C2, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ out, int64_t hw,
+                                                     float eps, int silu) {
+    __shared__ float red[4];
+    const int C = C1 + C2, cpg = C / 32;
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int64_t n = hw * cpg;
+    auto load = [&](int64_t e) -> float {
+        const int64_t pix = e / cpg;
+        const int c = g * cpg + (int)(e - pix * cpg);
+        return c < C1 ? x1[((int64_t)b * hw + pix) * C1 + c] : x2[((int64_t)b * hw + pix) * C2 + (c - C1)];
+    };
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) s += load(e);
+    const float mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) { const float d = load(e) - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)n + eps);
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const int64_t pix = e / cpg;
+        const int c = g * cpg + (int)(e - pix * cpg);
+        float y = (load(e) - mean) * rstd * gamma[c] + beta[c];
+        if (silu) y = y / (1.0f + expf(-y));
+        out[((int64_t)b * hw + pix) * C + c] = y;
+    }
+}
+
+// LayerNorm over C, fp32: one wave per row, exact two-pass statistics.
+__global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ out,
+                                                     int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    for (int c = lane; c < C; c += 64) out[row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// Attention, head dim 64, fp32 throughout: block = 64 queries of one (batch, head), one query per thread; keys and
+// values are staged through LDS 64 at a time and read by broadcast; online softmax per thread.
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, float* __restrict__ out, int heads,
+                                                      int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                                      float scale) {
+    __shared__ float Ks[64][64], Vs[64][64];
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int qi = blockIdx.x * 64 + threadIdx.x;
+    const bool qok = qi < Nq;
+    const float* qp = q + ((int64_t)b * Nq + (qok ? qi : 0)) * ldq + h * 64;
+    float qr[64], o[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) { qr[d] = qp[d] * scale; o[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < Nk; k0 += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 64; e += 64) {
+            const int r = e >> 6, d = e & 63;
+            const bool ok = k0 + r < Nk;
+            Ks[r][d] = ok ? k[((int64_t)b * Nk + k0 + r) * ldk + h * 64 + d] : 0.f;
+            Vs[r][d] = ok ? v[((int64_t)b * Nk + k0 + r) * ldv + h * 64 + d] : 0.f;
+        }
+        __syncthreads();
+        const int kn = Nk - k0 < 64 ? Nk - k0 : 64;
+        for (int j = 0; j < kn; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) s = fmaf(qr[d], Ks[j][d], s);
+            const float mn = fmaxf(m, s);
+            const float a = expf(m - mn), p = expf(s - mn);
+            l = l * a + p;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) o[d] = fmaf(p, Vs[j][d], o[d] * a);
+            m = mn;
+        }
+    }
+    if (qok) {
+        float* op = out + ((int64_t)b * Nq + qi) * ldo + h * 64;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) op[d] = o[d] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int nb,
+                                                               int C, int64_t hw) {
+    const int64_t total = (int64_t)nb * C * hw;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = idx % hw;
+        const int64_t r = idx / hw;
+        const int c = (int)(r % C);
+        const int64_t b = r / C;
+        out[(b * hw + pix) * C + c] = x[idx];
+    }
+}
+
+__global__ void timestep_embedding_f32_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int nb, int dim,
+                                              float max_period) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= half || b >= nb) return;
+    // ldm/utils.py:304-314: freq = exp(-ln(max_period) * i / half); [cos | sin]
+    const float freq = expf(-logf(max_period) * (float)i / (float)half);
+    const float arg = (float)t[b] * freq;
+    out[(int64_t)b * dim + i] = cosf(arg);
+    out[(int64_t)b * dim + half + i] = sinf(arg);
+}
+
+inline unsigned blocks_for(int64_t n, int64_t cap = 16384) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int sdmi_f32_split3(const float* x1, const float* x2, int32_t C1, int32_t C2, int64_t rows, void* out,
+                               int32_t Cp, void* stream) {
+    if (x1 == nullptr || out == nullptr || rows <= 0 || C1 <= 0 || C2 < 0) return SDMI_ERR_BAD_ARG;
+    if ((x2 == nullptr) != (C2 == 0) || Cp < C1 + C2) return SDMI_ERR_BAD_ARG;
+    if (Cp % 8 != 0) return SDMI_ERR_ALIGNMENT;
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks_for(rows * Cp)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x1, x2,
+                       C1, C2, rows, reinterpret_cast<unsigned short*>(out), Cp);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_f32_groupnorm(const float* x1, const float* x2, int32_t C1, int32_t C2, const float* gamma,
+                                  const float* beta, float* out, int32_t nb, int64_t hw, float eps, int32_t silu,
+                                  void* stream) {
+    if (x1 == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (nb <= 0 || hw <= 0 || C1 <= 0 || C2 < 0 || (x2 == nullptr) != (C2 == 0)) return SDMI_ERR_BAD_ARG;
+    if ((C1 + C2) % 32 != 0) return SDMI_ERR_ALIGNMENT;
+    hipLaunchKernelGGL(gn_f32_kernel, dim3(32, (unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x1, x2, C1,
+                       C2, gamma, beta, out, hw, eps, silu);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_f32_layernorm(const float* x, const float* gamma, const float* beta, float* out, int64_t rows,
+                                  int32_t C, float eps, void* stream) {
+    if (x == nullptr || gamma == nullptr || beta == nullptr || out == nullptr || rows <= 0 || C <= 0) return SDMI_ERR_BAD_ARG;
+    if ((rows + 3) / 4 > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ln_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       gamma, beta, out, rows, C, eps);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
+                                      int32_t Nq, int32_t Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                      float scale, void* stream) {
+    if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (nb <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return SDMI_ERR_BAD_ARG;
+    if (ldq < (int64_t)heads * 64 || ldk < (int64_t)heads * 64 || ldv < (int64_t)heads * 64 || ldo < (int64_t)heads * 64)
+        return SDMI_ERR_BAD_ARG;
+    if ((int64_t)nb * heads > 65535) return SDMI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((Nq + 63) / 64), (unsigned)(nb * heads)), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), q, k, v, out, heads, Nq, Nk, ldq, ldk, ldv, ldo, scale);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, void* stream) {
+    if (x == nullptr || out == nullptr || nb <= 0 || C <= 0 || hw <= 0) return SDMI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(blocks_for((int64_t)nb * C * hw)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, out, nb, C, hw);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_f32_timestep_embedding(const int64_t* t, float* out, int32_t nb, int32_t dim, float max_period,
+                                           void* stream) {
+    if (t == nullptr || out == nullptr || nb <= 0 || dim <= 0 || dim % 2 != 0) return SDMI_ERR_BAD_ARG;
+    const int half = dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_f32_kernel, dim3((unsigned)((half + 127) / 128), (unsigned)nb), dim3(128), 0,
+                       reinterpret_cast<hipStream_t>(stream), t, out, nb, dim, max_period);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}

@@ -31,7 +31,7 @@ namespace {
 
 // Zeros: the DMA source of out-of-image conv taps and padded rows / columns (the DMA cannot mask).  Long enough
 // that a tap's pointer can walk a whole channel run (Cin <= ZERO_ELEMS) without leaving it.
-constexpr int ZERO_ELEMS = 8192;
+constexpr int ZERO_ELEMS = 16384;
 __device__ const uint4 sdmi_zeros[ZERO_ELEMS / 8 + 1] = {};
 
 // Block tile BM x BN x BK with BN = 32*TN: TN = 4 (128 columns) or TN = 5 (160 columns; every UNet width is a
@@ -68,7 +68,7 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
                                            int64_t zoff_out, int64_t zoff_res) {
     if (p.act == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
     }
     if (p.bias != nullptr && p.bias_per_row) {
         const float b = p.bias[m];
@@ -85,7 +85,10 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
             for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += e[j];
         }
     }
-    if (p.res != nullptr) {
+    if (p.res != nullptr && p.res_f32) {
+        const float* r = reinterpret_cast<const float*>(p.res) + zoff_res + m * p.ld_res + n;
+        for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += r[j];
+    } else if (p.res != nullptr) {
         const unsigned short* r = reinterpret_cast<const unsigned short*>(p.res) + zoff_res + m * p.ld_res + n;
         if (full) {
             const uint2 rv = *reinterpret_cast<const uint2*>(r);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
     // Common case (no GEGLU, row-major output, N % 4 == 0, column bias): all residual / embedding quads of a row
     // block are requested before the first one is consumed, so the loads overlap instead of forming one
     // load -> wait -> store round trip per quad.
-    if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row) {
+    if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row && !p.res_f32) {
         const int64_t ncol0 = n0 + wn * (TN * 16) + 4 * fq;
         f32x4 bq[TN];
         bool nval[TN];
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
                 f32x4 v = acc[ni][mi] * p.alpha + bq[ni];
                 if (p.act == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+                    for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
                 }
                 if (p.emb != nullptr) v += eq[ni];
                 if (p.res != nullptr) {
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
                 if (n >= p.N) continue;
                 f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+                for (int j = 0; j < 4; ++j) v[j] *= p.out_kind != 0 ? gelu_erf_precise(g[j]) : gelu_erf_f(g[j]);
                 store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
             }
         }
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
                 g += *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+            for (int j = 0; j < 4; ++j) v[j] *= p.out_kind != 0 ? gelu_erf_precise(g[j]) : gelu_erf_f(g[j]);
         } else if (p.bias != nullptr && !p.bias_per_row) {
             for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
         }
@@ -612,6 +615,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if ((a->emb != nullptr || a->out_kind == 2) && a->rows_per_batch <= 0) return SDMI_ERR_BAD_ARG;
     if (a->emb != nullptr && (a->ld_emb % 4 != 0)) return SDMI_ERR_ALIGNMENT;
     if (a->res != nullptr && (a->ld_res % 4 != 0)) return SDMI_ERR_ALIGNMENT;
+    if (a->res_f32 && a->out_kind == 0) return SDMI_ERR_BAD_ARG;      // an fp32 residual goes with an fp32 output
     if (a->out_kind != 2 && (a->ld_out % 4 != 0)) return SDMI_ERR_ALIGNMENT;
     if (a->mode == 0) {
         if (a->lda % 8 != 0) return SDMI_ERR_ALIGNMENT;

@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("alpha", C.c_float),
         ("tile_n", C.c_int32),
         ("tile_m", C.c_int32),
+        ("res_f32", C.c_int32),
         ("stages", C.c_int32),
     ]
 
@@ -47,6 +48,12 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "sdmi_status_str": (C.c_char_p, [C.c_int]),
     "sdmi_abi_version": (C.c_int, []),
+    "sdmi_f32_split3": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp]),
+    "sdmi_f32_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp]),
+    "sdmi_f32_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "sdmi_f32_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "sdmi_f32_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
+    "sdmi_f32_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "sdmi_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "sdmi_gemm_tile_m": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32]),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),

@@ -57,7 +57,8 @@ def _round_up(x, m):
 class PackedWeight:
     """bf16 [Npad, Kpad] weight (K contiguous) + fp32 bias in the layout sdmi_gemm expects."""
 
-    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN):
+    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN, split_cp=0):
+        self.split_cp = split_cp  # fp32 mode: > 0 = weights hold six bf16 planes of this width per K group (split3)
         self.w = w              # bf16|fp16 [Npad, Kpad]
         self.tile_n = tile_n    # column tile the rows are padded for (128 | 160)
         self.dtype = w.dtype
@@ -81,11 +82,44 @@ def _pad_pack(w2d, dtype=BF16, tile_n=_BN):
     return out
 
 
+_SPLIT_PAD = 32       # fp32 mode: plane width padding (6 * 32 = 3 GEMM k-tiles, and a conv tap never straddles a k-tile)
+
+
+def _split_planes(w):
+    """fp32 [..., K] -> bf16 [..., 6, Kp]: weight planes (w0 w1 w0 w2 w1 w0) matching the activation planes
+    (x0 x0 x1 x0 x1 x2) of sdmi_f32_split3, with w = w0 + w1 + w2 exactly."""
+    k = w.shape[-1]
+    kp = _round_up(k, _SPLIT_PAD)
+    wz = torch.zeros(*w.shape[:-1], kp, dtype=torch.float32, device=w.device)
+    wz[..., :k] = w
+    w0 = wz.to(BF16)
+    r1 = wz - w0.float()
+    w1 = r1.to(BF16)
+    w2 = (r1 - w1.float()).to(BF16)
+    return torch.stack([w0, w1, w0, w2, w1, w0], dim=-2), kp
+
+
+def split3(x, cp, x2=None):
+    """fp32 [..., C] (optionally the concat [x | x2]) -> bf16 [..., 6*cp] piece planes (sdmi_f32_split3)."""
+    _require(x, torch.float32, "x")
+    _require(x2, torch.float32, "x2")
+    c1 = x.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    rows = x.numel() // c1
+    out = torch.empty(*x.shape[:-1], 6 * cp, dtype=BF16, device=x.device)
+    hip.check(hip.lib().sdmi_f32_split3(_p(x), _p(x2), c1, c2, rows, _p(out), cp, _stream()), "sdmi_f32_split3")
+    return out
+
+
 def pack_linear(weight, bias=None, dtype=BF16, tile_n=None):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
     w = weight.detach().reshape(weight.shape[0], -1).float()
     b = bias.detach().float().contiguous() if bias is not None else None
     tn = tile_n or _tile_n_for(w.shape[0])
+    if dtype == torch.float32:
+        planes, kp = _split_planes(w)
+        packed = _pad_pack(planes.reshape(w.shape[0], 6 * kp), BF16, tn)
+        return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn, split_cp=kp)
     packed = _pad_pack(w, dtype, tn)
     return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn)
 
@@ -97,6 +131,10 @@ def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None):
     if biases is not None:
         b = torch.cat([x.detach().float() for x in biases]).contiguous()
     tn = tile_n or _tile_n_for(w.shape[0])
+    if dtype == torch.float32:
+        planes, kp = _split_planes(w)
+        packed = _pad_pack(planes.reshape(w.shape[0], 6 * kp), BF16, tn)
+        return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn, split_cp=kp)
     packed = _pad_pack(w, dtype, tn)
     return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn)
 
@@ -109,8 +147,12 @@ def pack_geglu(weight, bias, dtype=BF16):
     assert inner % 16 == 0
     r = torch.arange(2 * inner, device=w.device)
     src = ((r % 32) // 16) * inner + (r // 32) * 16 + (r % 16)
-    packed = _pad_pack(w[src], dtype)
     b = bias.detach().float()[src].contiguous() if bias is not None else None
+    if dtype == torch.float32:
+        planes, kp = _split_planes(w[src])
+        packed = _pad_pack(planes.reshape(2 * inner, 6 * kp), BF16)
+        return PackedWeight(packed, b, inner, packed.shape[1], geglu=True, split_cp=kp)
+    packed = _pad_pack(w[src], dtype)
     return PackedWeight(packed, b, inner, packed.shape[1], geglu=True)
 
 
@@ -118,12 +160,16 @@ def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
     """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8."""
     w = weight.detach().float()
     cout, cin = w.shape[0], w.shape[1]
+    tn = tile_n or _tile_n_for(cout)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    if dtype == torch.float32:
+        planes, cp = _split_planes(w.permute(0, 2, 3, 1))              # [cout, 3, 3, 6, cp]: six planes inside every tap
+        packed = _pad_pack(planes.reshape(cout, 9 * 6 * cp), BF16, tn)
+        return PackedWeight(packed, b, cout, packed.shape[1], cin=6 * cp, tile_n=tn, split_cp=cp)
     cin_p = _round_up(cin, 8)
     wp = torch.zeros(cout, 3, 3, cin_p, dtype=torch.float32, device=w.device)
     wp[..., :cin] = w.permute(0, 2, 3, 1)
-    tn = tile_n or _tile_n_for(cout)
     packed = _pad_pack(wp.reshape(cout, 9 * cin_p), dtype, tn)
-    b = bias.detach().float().contiguous() if bias is not None else None
     return PackedWeight(packed, b, cout, packed.shape[1], cin=cin_p, tile_n=tn)
 
 
@@ -214,7 +260,8 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.emb = emb.data_ptr()
         a.ld_emb = emb.stride(0)
     if res is not None:
-        _require(res, pw.dtype, "res")
+        _require(res, torch.float32 if pw.split_cp else pw.dtype, "res")
+        a.res_f32 = 1 if pw.split_cp else 0
         a.res = res.data_ptr()
         a.ld_res = res.shape[-1]
     n_w = pw.n_out * (2 if pw.geglu else 1)
@@ -237,7 +284,12 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
 
 def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True):
     """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat).
-    out_dtype: None = the operand type, or torch.float32."""
+    out_dtype: None = the operand type, or torch.float32.  fp32 mode (pw.split_cp): x (and x2, res) are fp32, the
+    input is split into bf16 piece planes first and the output is fp32."""
+    if pw.split_cp:
+        x = split3(x, pw.split_cp, x2)
+        x2 = None
+        out_dtype = torch.float32
     _require(x, pw.dtype, "x")
     out_dtype = out_dtype or pw.dtype
     k1 = x.shape[-1]
@@ -267,7 +319,10 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
 
 def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False):
     """3x3 conv, pad 1, on an NHWC bf16 image [B, H, W, Cin]; optional fused nearest-x2 input gather,
-    time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC 16-bit, or fp32 NCHW."""
+    time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC 16-bit, or fp32 NCHW.
+    fp32 mode (pw.split_cp): x and res are fp32 NHWC, the output is fp32 NHWC."""
+    if pw.split_cp:
+        x = split3(x, pw.split_cp)
     _require(x, pw.dtype, "x")
     b, h, w, cin = x.shape
     if cin != pw.cin:
@@ -285,8 +340,8 @@ def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=Fa
     if out_nchw_f32:
         out = torch.empty(b, pw.n_out, ho, wo, dtype=torch.float32, device=x.device)
     else:
-        out = torch.empty(b, ho, wo, pw.n_out, dtype=pw.dtype, device=x.device)
-    keep = _fill_common(a, pw, out, True, emb, ho * wo, res, 0, 2 if out_nchw_f32 else 0, 1.0, m)
+        out = torch.empty(b, ho, wo, pw.n_out, dtype=torch.float32 if pw.split_cp else pw.dtype, device=x.device)
+    keep = _fill_common(a, pw, out, True, emb, ho * wo, res, 0, 2 if out_nchw_f32 else (1 if pw.split_cp else 0), 1.0, m)
     _run_gemm(a, "sdmi_gemm(conv3x3)")
     del keep
     return out
@@ -330,7 +385,17 @@ def gemm_nt_batched(a_mat, b_mat, out_dtype, alpha=1.0, bias_rows=None):
 
 
 def groupnorm(x1, gamma, beta, eps, silu, x2=None):
-    """GroupNorm(32)(+SiLU) over NHWC 16-bit; x2 = second half of a channel concat (read in place)."""
+    """GroupNorm(32)(+SiLU) over NHWC 16-bit (or fp32 in fp32 mode); x2 = second half of a channel concat (read in
+    place)."""
+    if x1.dtype == torch.float32:
+        _require(x1, torch.float32, "x1")
+        _require(x2, torch.float32, "x2")
+        b, c1 = x1.shape[0], x1.shape[-1]
+        c2 = x2.shape[-1] if x2 is not None else 0
+        out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=torch.float32, device=x1.device)
+        hip.check(hip.lib().sdmi_f32_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b,
+                                               x1.numel() // (b * c1), eps, 1 if silu else 0, _stream()), "sdmi_f32_groupnorm")
+        return out
     dt = _dt(x1.dtype)
     _require(x1, x1.dtype, "x1")
     _require(x2, x1.dtype, "x2")
@@ -349,6 +414,13 @@ def groupnorm(x1, gamma, beta, eps, silu, x2=None):
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
+    if x.dtype == torch.float32:
+        _require(x, torch.float32, "x")
+        out = torch.empty_like(x)
+        c = x.shape[-1]
+        hip.check(hip.lib().sdmi_f32_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, _stream()),
+                  "sdmi_f32_layernorm")
+        return out
     dt = _dt(x.dtype)
     _require(x, x.dtype, "x")
     c = x.shape[-1]
@@ -364,11 +436,15 @@ def layernorm(x, gamma, beta, eps=1e-5):
 def attention_d64(q, k, v, heads, nb, nq, nk, scale):
     """q: [nb*nq, >=heads*64] (may be a column slice of a fused qkv buffer), k/v: [nb*nk, ...].
     Row strides are taken from the tensors; the innermost stride must be 1."""
-    dt = _dt(q.dtype)
     for t, name in ((q, "q"), (k, "k"), (v, "v")):
         if t.dtype != q.dtype or not t.is_cuda or t.stride(-1) != 1:
             raise hip.SdmiError(f"attention: bad {name}")
     out = torch.empty(nb * nq, heads * 64, dtype=q.dtype, device=q.device)
+    if q.dtype == torch.float32:
+        hip.check(hip.lib().sdmi_f32_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
+                                                   v.stride(0), out.stride(0), scale, _stream()), "sdmi_f32_attention_d64")
+        return out
+    dt = _dt(q.dtype)
     hip.check(hip.lib().sdmi_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
                                            v.stride(0), out.stride(0), scale, dt, _stream()), "sdmi_attention_d64")
     return out
@@ -400,9 +476,15 @@ def softmax_cols(st, out_dtype=BF16):
 
 
 def nchw_to_nhwc(x, cpad=None, scale=1.0, dtype=BF16):
-    """fp32 [B, C, H, W] -> 16-bit [B, H, W, Cpad]."""
+    """fp32 [B, C, H, W] -> 16-bit [B, H, W, Cpad] (fp32 mode: fp32 [B, H, W, C], no padding)."""
     _require(x, torch.float32, "x")
     b, c, h, w = x.shape
+    if dtype == torch.float32:
+        if scale != 1.0:
+            raise hip.SdmiError("nchw_to_nhwc: scale is not supported in fp32 mode")
+        out = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().sdmi_f32_nchw_to_nhwc(_p(x), _p(out), b, c, h * w, _stream()), "sdmi_f32_nchw_to_nhwc")
+        return out
     cpad = cpad or _round_up(c, 8)
     out = torch.empty(b, h, w, cpad, dtype=dtype, device=x.device)
     hip.check(hip.lib().sdmi_nchw_f32_to_nhwc(_p(x), _p(out), b, c, cpad, h * w, scale, _dt(dtype), _stream()),
@@ -412,6 +494,8 @@ def nchw_to_nhwc(x, cpad=None, scale=1.0, dtype=BF16):
 
 def cast_f32(x, dtype=BF16):
     _require(x, torch.float32, "x")
+    if dtype == torch.float32:
+        return x
     out = torch.empty(x.shape, dtype=dtype, device=x.device)
     hip.check(hip.lib().sdmi_cast_f32(_p(x), _p(out), x.numel(), _dt(dtype), _stream()), "sdmi_cast_f32")
     return out
@@ -424,6 +508,10 @@ def to_bf16(x):
 def timestep_embedding(t, dim, max_period=10000.0, dtype=BF16):
     _require(t, torch.int64, "t")
     out = torch.empty(t.shape[0], dim, dtype=dtype, device=t.device)
+    if dtype == torch.float32:
+        hip.check(hip.lib().sdmi_f32_timestep_embedding(_p(t), _p(out), t.shape[0], dim, max_period, _stream()),
+                  "sdmi_f32_timestep_embedding")
+        return out
     hip.check(hip.lib().sdmi_timestep_embedding(_p(t), _p(out), t.shape[0], dim, max_period, _dt(dtype), _stream()),
               "sdmi_timestep_embedding")
     return out

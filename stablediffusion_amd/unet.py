@@ -284,10 +284,11 @@ class UNetModel(nn.Module):
         if dev.type != "cuda":
             raise ops.hip.SdmiError("HIP UNetModel.forward needs the model on a GPU (model.cuda()); "
                                     "there is no CPU fallback")
-        if self.compute_dtype not in ops.HALF_TYPES:
-            raise NotImplementedError("HIP UNetModel: fp32 compute (use_fp16=False, use_bf16=False) is not built; "
-                                      "set use_bf16=True (bf16 MFMA) or use_fp16=True (f16 MFMA)")
+        # dtype policy of the reference (openai_model.py:602-603): fp16 / bf16 MFMA operands, or - neither flag set -
+        # the fp32 mode: fp32 activations, contractions through the 3 x bf16 split (csrc/sdmi_f32.hip)
         cd = self.compute_dtype
+        if cd not in ops.HALF_TYPES and cd != torch.float32:
+            raise NotImplementedError(f"HIP UNetModel: unsupported compute dtype {cd}")
         pk = {}
         f32 = lambda t: t.detach().float().contiguous()
         te = self.time_embedding

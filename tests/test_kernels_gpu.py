@@ -420,3 +420,80 @@ def test_fp16_operand_type(dev, dt):
     assert rel_err(out, _attn_ref(qd(qq), qd(kk), qd(vv), nb, heads, nq, nk, 0.125)) < 2e-3
     assert torch.equal(ops.cast_f32(x, dt), x.to(dt))
     assert ops.nchw_to_nhwc(rnd((1, 4, 8, 8), dev, 14), dtype=dt).dtype == dt
+
+
+# ----------------------------------------------------------------------------- fp32 mode
+
+
+def test_fp32_split3_is_exact(dev):
+    """x = x0 + x1 + x2 exactly (three bf16 pieces carry the 24 mantissa bits), planes laid out x0 x0 x1 x0 x1 x2,
+    padded channels zero; the two-pointer form equals the concatenation."""
+    ops = _ops()
+    x1, x2 = rnd((37, 40), dev, 1, 3.0), rnd((37, 24), dev, 2, 1e-3)
+    cp = 64
+    out = ops.split3(x1, cp, x2).float().reshape(37, 6, cp)
+    x = torch.cat([x1, x2], -1)
+    assert torch.equal(out[:, 0], out[:, 1]) and torch.equal(out[:, 0], out[:, 3]) and torch.equal(out[:, 2], out[:, 4])
+    assert torch.equal((out[:, 0] + out[:, 2] + out[:, 5])[:, :64], x)
+    assert torch.equal(out[:, 0, :64], x.to(BF16).float())
+
+
+def test_fp32_mode_ops(dev):
+    """Every op of the fp32 mode against fp32 PyTorch: GEMM family through the split (<= 2e-6 of max|ref|, fp32
+    accumulation order aside), norms / attention / activations in plain fp32."""
+    ops = _ops()
+    f32 = torch.float32
+    m, k, n = 300, 320, 640
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    res = rnd((m, n), dev, 4)
+    out = ops.linear(x, ops.pack_linear(w, b, dtype=f32), res=res)
+    assert out.dtype == f32 and rel_err(out, F.linear(x, w, b) + res) < 2e-6
+    out = ops.linear(x, ops.pack_linear(w, b, dtype=f32), act=1)
+    assert rel_err(out, F.silu(F.linear(x, w, b))) < 2e-6
+    x2 = rnd((m, 96), dev, 5)
+    w2 = rnd((n, k + 96), dev, 6, 0.05)
+    out = ops.linear(x, ops.pack_linear(w2, None, dtype=f32), x2=x2)
+    assert rel_err(out, F.linear(torch.cat([x, x2], -1), w2)) < 2e-6
+    wg, bg = rnd((8 * k, k), dev, 7, k ** -0.5), rnd((8 * k,), dev, 8)
+    out = ops.linear(x, ops.pack_geglu(wg, bg, dtype=f32))
+    a, gate = F.linear(x, wg, bg).chunk(2, dim=-1)
+    assert rel_err(out, a * F.gelu(gate)) < 2e-6
+    for stride, ups in ((1, False), (2, False), (1, True)):
+        xi = rnd((2, 40, 12, 10), dev, 9)
+        wt, bias = rnd((96, 40, 3, 3), dev, 10, 1 / 19), rnd((96,), dev, 11)
+        emb = rnd((2, 96), dev, 12)
+        out = ops.conv3x3(xi.permute(0, 2, 3, 1).contiguous(), ops.pack_conv3x3(wt, bias, dtype=f32), stride=stride,
+                          upsample=ups, emb=emb)
+        xin = F.interpolate(xi, scale_factor=2, mode="nearest") if ups else xi
+        ref = F.conv2d(xin, wt, bias, stride=stride, padding=1) + emb[:, :, None, None]
+        assert out.dtype == f32 and rel_err(out.permute(0, 3, 1, 2), ref) < 2e-6
+    out = ops.conv3x3(xi.permute(0, 2, 3, 1).contiguous(), ops.pack_conv3x3(wt[:4], bias[:4], dtype=f32), out_nchw_f32=True)
+    assert rel_err(out, F.conv2d(xi, wt[:4], bias[:4], padding=1)) < 2e-6
+    # norms
+    g1, g2 = rnd((2, 8, 8, 64), dev, 13, 2.0) + 0.5, rnd((2, 8, 8, 32), dev, 14)
+    gam, bet = rnd((96,), dev, 15), rnd((96,), dev, 16)
+    out = ops.groupnorm(g1, gam, bet, 1e-5, True, x2=g2)
+    ref = F.silu(F.group_norm(torch.cat([g1, g2], -1).permute(0, 3, 1, 2), 32, gam, bet, 1e-5)).permute(0, 2, 3, 1)
+    assert rel_err(out, ref) < 2e-6
+    xl = rnd((77, 320), dev, 17, 3.0) + 1.0
+    gl, bl = rnd((320,), dev, 18), rnd((320,), dev, 19)
+    assert rel_err(ops.layernorm(xl, gl, bl, 1e-5), F.layer_norm(xl, (320,), gl, bl, 1e-5)) < 2e-6
+    # attention (fused qkv buffer, ragged key count)
+    nb, heads, nq, nk = 2, 3, 70, 77
+    q = rnd((nb * nq, heads * 64), dev, 20)
+    kv = rnd((nb * nk, 2 * heads * 64), dev, 21)
+    out = ops.attention_d64(q, kv[:, :heads * 64], kv[:, heads * 64:], heads, nb, nq, nk, 0.125)
+    qh = q.reshape(nb, nq, heads, 64).permute(0, 2, 1, 3)
+    kh = kv[:, :heads * 64].reshape(nb, nk, heads, 64).permute(0, 2, 1, 3)
+    vh = kv[:, heads * 64:].reshape(nb, nk, heads, 64).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, heads * 64)
+    assert rel_err(out, ref) < 2e-6
+    # layout + timestep embedding
+    xn = rnd((2, 4, 6, 5), dev, 22)
+    assert torch.equal(ops.nchw_to_nhwc(xn, dtype=f32), xn.permute(0, 2, 3, 1).contiguous())
+    t = torch.tensor([0, 17, 981], device=dev)
+    te = ops.timestep_embedding(t, 320, dtype=f32)
+    freqs = torch.exp(-math.log(10000) * torch.arange(160, device=dev, dtype=f32) / 160)
+    args = t[:, None].float() * freqs[None]
+    # arguments reach ~1e3 rad: one ulp of the fp32 frequency already moves cos/sin by ~6e-5
+    assert rel_err(te, torch.cat([torch.cos(args), torch.sin(args)], -1)) < 2e-4

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../stablediffusion_amd/csrc"
 objs=""
-for f in sdmi_api sdmi_gemm sdmi_norm sdmi_elem sdmi_attn; do
+for f in sdmi_api sdmi_gemm sdmi_norm sdmi_elem sdmi_attn sdmi_f32; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value "$@" -c $f.hip -o /tmp/ab_$f.o
   objs="$objs /tmp/ab_$f.o"
 done
