@@ -93,6 +93,8 @@ typedef struct sdmi_gemm_args {
     float alpha;
     int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it */
     int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 */
+    int32_t asym_pad;                   /* mode 1: 0 = zero pad 1 on every side; 1 = pad bottom/right only - the VAE
+                                           encoder's DownSample, F.pad(x, (0,1,0,1)) + conv stride 2 (model.py:87,99-102) */
     int32_t res_f32;                    /* 1: `res` is fp32 (only with an fp32 out_kind) - the fp32 mode of the path */
     int32_t stages;                     /* LDS ring depth: 0 | 3 = three stages; 2 (128-row tile only) = two stages,
                                            two blocks per CU - for short K */
@@ -199,6 +201,13 @@ int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float
                            void* stream);
 int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, void* stream);
 int sdmi_f32_timestep_embedding(const int64_t* t, float* out, int32_t nb, int32_t dim, float max_period, void* stream);
+
+/* DiagonalGaussianDistribution (ldm/modules/distribution/distribution.py:10-43) on fp32 NCHW moments
+ * [nb, 2C, hw]: mean = first half, log_var = second half clamped to [-30, 20], std = exp(log_var / 2),
+ * var = exp(log_var) (std = var = 0 when deterministic); sdmi_mul_add gives the sample mean + std * noise. */
+int sdmi_diag_gaussian(const float* parameters, float* mean, float* log_var, float* stdv, float* var, int32_t nb, int32_t C,
+                       int64_t hw, int32_t deterministic, void* stream);
+int sdmi_mul_add(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 
 int sdmi_image_to_u8(const float* x, uint8_t* out, int32_t nb, int32_t C, int64_t hw, void* stream);
 

@@ -331,3 +331,50 @@ def vae_decode(sd, ddcfg, z, vae_attn="reference"):
     """AutoencoderKL.decode (absent from the reference, autoencoder.py:54 only builds
     post_quant_conv): z -> post_quant_conv (1x1) -> decoder."""
     return decoder_forward(sd, ddcfg, _conv(sd, "post_quant_conv.", z), p="decoder.", vae_attn=vae_attn)
+
+
+# ----------------------------------------------------------------------------- VAE encoder (SURVEY.md §8(f) rank 4)
+
+
+def vae_down_sample(sd, p, x):
+    """DownSample.forward with with_conv=True, model.py:76-106: zero pad (left 0, right 1, top 0, bottom 1), then
+    conv3x3 stride 2 without padding."""
+    x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+    w, b = _q(sd[p + "conv.weight"].float()), sd[p + "conv.bias"].float()
+    return F.conv2d(_q(x), w, b, stride=2, padding=0)
+
+
+def encoder_forward(sd, ddcfg, x, p="", vae_attn="reference"):
+    """Encoder.forward, model.py:240-279: conv_in -> per level [ResnetBlock (+Attn)] x num_res_blocks, DownSample
+    between levels -> mid (Res, Attn, Res) -> GroupNorm -> swish -> conv_out (2*z_channels moments)."""
+    ch_mult = list(ddcfg["ch_mult"])
+    nrb = ddcfg["num_res_blocks"]
+    h = _conv(sd, p + "conv_in.", x)
+    for lvl in range(len(ch_mult)):
+        for i in range(nrb):
+            h = vae_resnet_block(sd, f"{p}down.{lvl}.block.{i}.", h)
+            if f"{p}down.{lvl}.attn.{i}.norm.weight" in sd:
+                h = vae_attn_block(sd, f"{p}down.{lvl}.attn.{i}.", h, vae_attn)
+        if lvl != len(ch_mult) - 1:
+            h = vae_down_sample(sd, f"{p}down.{lvl}.downsample.", h)
+    h = vae_resnet_block(sd, p + "mid.block_1.", h)
+    h = vae_attn_block(sd, p + "mid.attn_1.", h, vae_attn)
+    h = vae_resnet_block(sd, p + "mid.block_2.", h)
+    h = swish(_gn(sd, p + "norm_out.", h, 1e-6))
+    return _conv(sd, p + "conv_out.", h)
+
+
+def diagonal_gaussian(parameters, noise=None):
+    """DiagonalGaussianDistribution, distribution.py:10-43: (mean, log_var clamped to [-30, 20], std, var) and the
+    reparameterised sample mean + std * noise (mode = mean)."""
+    mean, log_var = torch.chunk(parameters, 2, dim=1)
+    log_var = torch.clamp(log_var, -30.0, 20.0)
+    std, var = torch.exp(0.5 * log_var), torch.exp(log_var)
+    sample = mean + std * noise if noise is not None else None
+    return dict(mean=mean, log_var=log_var, std=std, var=var, sample=sample)
+
+
+def vae_encode(sd, ddcfg, x, vae_attn="reference"):
+    """AutoencoderKL.encode (absent from the reference, autoencoder.py builds encoder + quant_conv only):
+    x -> encoder -> quant_conv (1x1) -> moments."""
+    return _conv(sd, "quant_conv.", encoder_forward(sd, ddcfg, x, p="encoder.", vae_attn=vae_attn))

@@ -284,6 +284,45 @@ __global__ __launch_bounds__(256) void lincomb4_kernel(const float* __restrict__
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void diag_gaussian_kernel(const float* __restrict__ prm, float* __restrict__ mean,
+                                                            float* __restrict__ log_var, float* __restrict__ stdv,
+                                                            float* __restrict__ var, int nb, int C, int64_t hw, int det) {
+    const int64_t per = (int64_t)C * hw, total = (int64_t)nb * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per, r = i - b * per;
+        const float m = prm[b * 2 * per + r];
+        const float lv = fminf(fmaxf(prm[b * 2 * per + per + r], -30.0f), 20.0f);
+        mean[i] = m;
+        log_var[i] = lv;
+        stdv[i] = det ? 0.f : expf(0.5f * lv);
+        var[i] = det ? 0.f : expf(lv);
+    }
+}
+__global__ __launch_bounds__(256) void mul_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ c, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i] * c[i];
+}
+}  // namespace
+
+extern "C" int sdmi_diag_gaussian(const float* parameters, float* mean, float* log_var, float* stdv, float* var, int32_t nb,
+                                  int32_t C, int64_t hw, int32_t deterministic, void* stream) {
+    if (parameters == nullptr || mean == nullptr || log_var == nullptr || stdv == nullptr || var == nullptr) return SDMI_ERR_BAD_ARG;
+    if (nb <= 0 || C <= 0 || hw <= 0) return SDMI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(diag_gaussian_kernel, dim3(grid_for((int64_t)nb * C * hw)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), parameters, mean, log_var, stdv, var, nb, C, hw, deterministic);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_mul_add(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
+    if (a == nullptr || b == nullptr || c == nullptr || out == nullptr || n <= 0) return SDMI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mul_add_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, c, out, n);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
 extern "C" int sdmi_lincomb4(const float* x0, const float* x1, const float* x2, const float* x3, float w0, float w1,
                              float w2, float w3, float* out, int64_t n, void* stream) {
     if (x0 == nullptr || out == nullptr || n <= 0) return SDMI_ERR_BAD_ARG;

@@ -218,8 +218,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
             const int rem = (int)(m - b * hw);
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_off[i] = b * (int64_t)p.H * p.W_in;
-            iy0[i] = rvalid[i] ? oy * p.stride - 1 : -(1 << 20);
-            ix0[i] = ox * p.stride - 1;
+            const int pad_lo = p.asym_pad ? 0 : 1;          // asym_pad: zero pad on the bottom / right only
+            iy0[i] = rvalid[i] ? oy * p.stride - pad_lo : -(1 << 20);
+            ix0[i] = ox * p.stride - pad_lo;
         }
     }
     const int Hl = p.H << p.upsample, Wl = p.W_in << p.upsample;
@@ -633,7 +634,9 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         if (a->K < 9 * (int64_t)a->Cin) return SDMI_ERR_BAD_ARG;
         // output geometry must match the (possibly upsampled) input
         const int Hl = a->H << a->upsample, Wl = a->W_in << a->upsample;
-        if ((Hl + 2 - 3) / a->stride + 1 != a->Ho || (Wl + 2 - 3) / a->stride + 1 != a->Wo) return SDMI_ERR_BAD_ARG;
+        const int padsum = a->asym_pad ? 1 : 2;
+        if (a->asym_pad != 0 && a->asym_pad != 1) return SDMI_ERR_BAD_ARG;
+        if ((Hl + padsum - 3) / a->stride + 1 != a->Ho || (Wl + padsum - 3) / a->stride + 1 != a->Wo) return SDMI_ERR_BAD_ARG;
         if (a->A2 != nullptr) return SDMI_ERR_BAD_ARG;
     }
     sdmi_gemm_args p = *a;

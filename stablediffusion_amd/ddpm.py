@@ -20,6 +20,11 @@ from .util import instantiate_from_config, count_params
 _COND_KEYS = {"crossattn": "cross_attn", "cross_attn": "cross_attn", None: None}
 
 
+def ops_lincomb(terms):
+    from . import ops
+    return ops.lincomb(terms)
+
+
 class DiffusionWrapper(nn.Module):
     def __init__(self, diffusion_model_config, condition_key):
         super().__init__()
@@ -185,6 +190,18 @@ class LatentDiffusion(nn.Module):
         if not isinstance(cond, (list, tuple)):
             cond = [cond]
         return self.model(x_noisy, t, condition_cross_attn=list(cond))
+
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        """image fp32 NCHW in [-1, 1] -> DiagonalGaussianDistribution posterior (img2img / inpainting entry;
+        upstream ddpm.py encode_first_stage, absent from the reference)."""
+        return self.first_stage_model.encode(x)
+
+    @torch.no_grad()
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        """scale_factor * posterior.sample() (or the tensor itself), as upstream's get_first_stage_encoding."""
+        z = encoder_posterior.sample(noise) if hasattr(encoder_posterior, "sample") else encoder_posterior
+        return ops_lincomb([(float(self.scale_factor), z)])
 
     @torch.no_grad()
     def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):

@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("alpha", C.c_float),
         ("tile_n", C.c_int32),
         ("tile_m", C.c_int32),
+        ("asym_pad", C.c_int32),
         ("res_f32", C.c_int32),
         ("stages", C.c_int32),
     ]
@@ -48,6 +49,8 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "sdmi_status_str": (C.c_char_p, [C.c_int]),
     "sdmi_abi_version": (C.c_int, []),
+    "sdmi_diag_gaussian": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "sdmi_mul_add": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "sdmi_f32_split3": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "sdmi_f32_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp]),
     "sdmi_f32_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),

@@ -282,7 +282,8 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     return None
 
 
-def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True):
+def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True,
+           out_nchw_f32=None):
     """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat).
     out_dtype: None = the operand type, or torch.float32.  fp32 mode (pw.split_cp): x (and x2, res) are fp32, the
     input is split into bf16 piece planes first and the output is fp32."""
@@ -310,14 +311,19 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
         if _round_up(k1, _BK) != pw.k or k1 % 8:
             raise hip.SdmiError(f"linear: K mismatch ({k1} vs packed {pw.k})")
         a.k_valid = k1          # K padding of the packed weight: columns past k1 read as zero
-    out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
-    keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
+    if out_nchw_f32 is not None:          # (B, H, W): rows are pixels of B images; write fp32 [B, N, H, W]
+        nb_, hh_, ww_ = out_nchw_f32
+        out = torch.empty(nb_, pw.n_out, hh_, ww_, dtype=torch.float32, device=x.device)
+        keep = _fill_common(a, pw, out, bias, emb, hh_ * ww_, res, act, 2, alpha, m)
+    else:
+        out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
+        keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
     _run_gemm(a, "sdmi_gemm(linear)")
     del keep
     return out
 
 
-def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False):
+def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False, asym_pad=False):
     """3x3 conv, pad 1, on an NHWC bf16 image [B, H, W, Cin]; optional fused nearest-x2 input gather,
     time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC 16-bit, or fp32 NCHW.
     fp32 mode (pw.split_cp): x and res are fp32 NHWC, the output is fp32 NHWC."""
@@ -328,13 +334,15 @@ def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=Fa
     if cin != pw.cin:
         raise hip.SdmiError(f"conv3x3: Cin mismatch ({cin} vs packed {pw.cin})")
     hl, wl = (2 * h, 2 * w) if upsample else (h, w)
-    ho, wo = (hl + 2 - 3) // stride + 1, (wl + 2 - 3) // stride + 1
+    padsum = 1 if asym_pad else 2        # asym_pad: zero pad bottom/right only (VAE encoder DownSample)
+    ho, wo = (hl + padsum - 3) // stride + 1, (wl + padsum - 3) // stride + 1
     a = hip.GemmArgs()
     a.mode = 1
     a.A = x.data_ptr()
     a.H, a.W_in, a.Cin, a.Ho, a.Wo = h, w, cin, ho, wo
     a.stride = stride
     a.upsample = 1 if upsample else 0
+    a.asym_pad = 1 if asym_pad else 0
     m = b * ho * wo
     a.M = m
     if out_nchw_f32:
@@ -546,6 +554,26 @@ def lincomb(terms):
     ptr = [_p(x) for x in xs] + [None] * (4 - len(xs))
     w = [float(t[0]) for t in terms] + [0.0] * (4 - len(terms))
     hip.check(hip.lib().sdmi_lincomb4(*ptr, *w, _p(out), out.numel(), _stream()), "sdmi_lincomb4")
+    return out
+
+
+def diag_gaussian(parameters, deterministic=False):
+    """fp32 [B, 2C, h, w] moments -> (mean, log_var clamped to [-30, 20], std, var), each fp32 [B, C, h, w]."""
+    _require(parameters, torch.float32, "parameters")
+    b, c2, h, w = parameters.shape
+    c = c2 // 2
+    outs = [torch.empty(b, c, h, w, dtype=torch.float32, device=parameters.device) for _ in range(4)]
+    hip.check(hip.lib().sdmi_diag_gaussian(_p(parameters), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), b, c, h * w,
+                                           1 if deterministic else 0, _stream()), "sdmi_diag_gaussian")
+    return tuple(outs)
+
+
+def lincomb_mul_add(a, b, c):
+    """a + b * c elementwise (fp32): the reparameterised sample mean + std * noise."""
+    for t, n in ((a, "a"), (b, "b"), (c, "c")):
+        _require(t, torch.float32, n)
+    out = torch.empty_like(a)
+    hip.check(hip.lib().sdmi_mul_add(_p(a), _p(b), _p(c), _p(out), a.numel(), _stream()), "sdmi_mul_add")
     return out
 
 

@@ -55,6 +55,15 @@ class UpSample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
 
 
+class DownSample(nn.Module):
+    """model.py:76-106 with with_conv=True: F.pad(x, (0, 1, 0, 1)) then conv3x3 stride 2 without padding (the HIP conv
+    folds the one-sided padding into its bounds check: ops.conv3x3(..., stride=2, asym_pad=True))."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, stride=2, padding=0)
+
+
 def _pad_rows(t, mult):
     """[Z, R, K] -> rows padded with zeros to a multiple of `mult` (only tiny test shapes need it)."""
     r = t.shape[1]
@@ -66,51 +75,11 @@ def _pad_rows(t, mult):
     return out
 
 
-class Decoder(nn.Module):
-    def __init__(self, *, channels=None, out_channels=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions,
-                 dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False,
-                 tanh_out=False, use_linear_attn=False, attn_type="vanilla", ch=None, out_ch=None,
-                 vae_attn="reference", compute_dtype=torch.bfloat16, **ignorekwargs):
-        super().__init__()
-        self.compute_dtype = compute_dtype
-        channels = channels if channels is not None else ch
-        out_channels = out_channels if out_channels is not None else out_ch
-        if channels is None or out_channels is None:
-            raise TypeError("Decoder needs channels/ch and out_channels/out_ch")
-        if use_linear_attn or attn_type not in ("vanilla",) or not resamp_with_conv or give_pre_end or tanh_out:
-            raise NotImplementedError("HIP Decoder: only the SD2 configuration (vanilla attention, conv resample) is built")
-        self.channels = channels
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.resolution = resolution
-        self.in_channels = in_channels
-        self.vae_attn = vae_attn
-        block_in = channels * ch_mult[-1]
-        curr_res = resolution // 2 ** (self.num_resolutions - 1)
-        self.z_shape = (1, z_channels, curr_res, curr_res)
-        self.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(block_in, block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(block_in, block_in)
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_out = channels * ch_mult[i_level]
-            for _ in range(num_res_blocks + 1):
-                block.append(ResnetBlock(block_in, block_out))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(AttnBlock(block_in))
-            up = nn.Module()
-            up.block, up.attn = block, attn
-            if i_level != 0:
-                up.up_sample = UpSample(block_in)
-                curr_res *= 2
-            self.up.insert(0, up)
-        self.norm_out = _gn(block_in)              # repair B5
-        self.conv_out = nn.Conv2d(block_in, out_channels, 3, padding=1)
-        self._pack = None
+class _VaeNet(nn.Module):
+    """What Encoder and Decoder share on the HIP path: weight packing, ResnetBlock, AttnBlock, dtype policy."""
+
+    vae_attn = "reference"
+    compute_dtype = torch.bfloat16
 
     def _apply(self, fn, *a, **kw):
         self._pack = None
@@ -122,7 +91,7 @@ class Decoder(nn.Module):
     def set_compute_dtype(self, dtype):
         """bf16 or fp16 storage / MFMA operand type (LatentDiffusion aligns it with the UNet's policy)."""
         if dtype not in ops.HALF_TYPES:
-            raise NotImplementedError("HIP Decoder: compute dtype must be torch.bfloat16 or torch.float16")
+            raise NotImplementedError("HIP VAE: compute dtype must be torch.bfloat16 or torch.float16")
         if dtype != self.compute_dtype:
             self.compute_dtype = dtype
             self._pack = None
@@ -131,7 +100,7 @@ class Decoder(nn.Module):
     def _build_pack(self):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
-            raise ops.hip.SdmiError("HIP Decoder.forward needs the model on a GPU; there is no CPU fallback")
+            raise ops.hip.SdmiError("HIP VAE forward needs the model on a GPU; there is no CPU fallback")
         f32 = lambda t: t.detach().float().contiguous()
         pk = {}
         cd = self.compute_dtype
@@ -151,7 +120,7 @@ class Decoder(nn.Module):
                     "wv": m.v.weight.detach().reshape(c, c).to(cd).contiguous()[None], "bv": f32(m.v.bias),
                     "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias, dtype=cd),
                 }
-            elif isinstance(m, UpSample):
+            elif isinstance(m, (UpSample, DownSample)):
                 pk[id(m)] = ops.pack_conv3x3(m.conv.weight, m.conv.bias, dtype=cd)
         pk["conv_in"] = ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, dtype=cd)
         pk["norm_out"] = (f32(self.norm_out.weight), f32(self.norm_out.bias))
@@ -208,6 +177,139 @@ class Decoder(nn.Module):
         out = ops.linear(o.reshape(b * n, c), e["proj"], res=h.reshape(b * n, c))
         return out.reshape(b, hh, ww, c)
 
+
+class Encoder(_VaeNet):
+    """VAE Encoder on the HIP kernels (model.py:145-279): image -> 2*z_channels moments."""
+
+    def __init__(self, *, channels=None, out_channels=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions,
+                 dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True,
+                 use_linear_attn=False, attn_type="vanilla", ch=None, out_ch=None, vae_attn="reference",
+                 compute_dtype=torch.bfloat16, **ignore_kwargs):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        channels = channels if channels is not None else ch
+        if channels is None:
+            raise TypeError("Encoder needs channels/ch")
+        if use_linear_attn or attn_type not in ("vanilla",) or not resamp_with_conv:
+            raise NotImplementedError("HIP Encoder: only the SD2 configuration (vanilla attention, conv resample) is built")
+        self.channels = channels
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.vae_attn = vae_attn
+        self.conv_in = nn.Conv2d(in_channels, channels, 3, padding=1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = channels
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in = channels * in_ch_mult[i_level]
+            block_out = channels * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = DownSample(block_in)
+                curr_res //= 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.norm_out = _gn(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
+        self._pack = None
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: fp32 NCHW image [B, in_channels, H, W] -> 16-bit NHWC moments [B, H/f, W/f, 2*z_channels] (model.py:240-279)."""
+        pk = self._pack or self._build_pack()
+        h = ops.nchw_to_nhwc(x.float().contiguous(), dtype=self.compute_dtype)       # channels padded 3 -> 8
+        h = ops.conv3x3(h, pk["conv_in"])
+        for i_level in range(self.num_resolutions):
+            lvl = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = self._resnet(pk, lvl.block[i_block], h)
+                if len(lvl.attn) > 0:
+                    h = self._attn(pk, lvl.attn[i_block], h)
+            if i_level != self.num_resolutions - 1:
+                h = ops.conv3x3(h, pk[id(lvl.downsample)], stride=2, asym_pad=True)
+        h = self._resnet(pk, self.mid.block_1, h)
+        h = self._attn(pk, self.mid.attn_1, h)
+        h = self._resnet(pk, self.mid.block_2, h)
+        n = ops.groupnorm(h, pk["norm_out"][0], pk["norm_out"][1], 1e-6, True)
+        return ops.conv3x3(n, pk["conv_out"])
+
+
+class DiagonalGaussianDistribution(object):
+    """distribution.py:10-43 on device tensors: parameters fp32 NCHW [B, 2C, h, w] -> mean / log_var (clamped to
+    [-30, 20]) / std / var views computed by sdmi_diag_gaussian; sample() = mean + std * N(0, 1); mode() = mean."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.deterministic = deterministic
+        self.mean, self.log_var, self.std, self.var = ops.diag_gaussian(parameters, deterministic)
+
+    def sample(self, noise=None):
+        noise = torch.randn_like(self.mean) if noise is None else noise
+        return ops.lincomb_mul_add(self.mean, self.std, noise)
+
+    def mode(self):
+        return self.mean
+
+
+class Decoder(_VaeNet):
+    def __init__(self, *, channels=None, out_channels=None, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions,
+                 dropout=0.0, resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False,
+                 tanh_out=False, use_linear_attn=False, attn_type="vanilla", ch=None, out_ch=None,
+                 vae_attn="reference", compute_dtype=torch.bfloat16, **ignorekwargs):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        channels = channels if channels is not None else ch
+        out_channels = out_channels if out_channels is not None else out_ch
+        if channels is None or out_channels is None:
+            raise TypeError("Decoder needs channels/ch and out_channels/out_ch")
+        if use_linear_attn or attn_type not in ("vanilla",) or not resamp_with_conv or give_pre_end or tanh_out:
+            raise NotImplementedError("HIP Decoder: only the SD2 configuration (vanilla attention, conv resample) is built")
+        self.channels = channels
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.vae_attn = vae_attn
+        block_in = channels * ch_mult[-1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = channels * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.up_sample = UpSample(block_in)
+                curr_res *= 2
+            self.up.insert(0, up)
+        self.norm_out = _gn(block_in)              # repair B5
+        self.conv_out = nn.Conv2d(block_in, out_channels, 3, padding=1)
+        self._pack = None
+
     @torch.no_grad()
     def forward(self, z, scale=1.0):
         """z: fp32 NCHW latent [B, z_channels, h, w] (or an already-NHWC bf16 tensor from decode()) ->
@@ -243,14 +345,15 @@ class AutoencoderKL(nn.Module):
         self.image_key = image_key
         self.learn_log_var = learn_log_var
         self.embedding_dim = embedding_dim
-        # The encoder half (img2img / training only) is outside the denoising hot path.
-        self.encoder = None
+        # encoder half: img2img / inpainting; autoencoder.py:44-54
+        self.encoder = Encoder(vae_attn=vae_attn, compute_dtype=compute_dtype, **dd_config)
         self.decoder = Decoder(vae_attn=vae_attn, compute_dtype=compute_dtype, **dd_config)
         self.loss = instantiate_from_config(loss_config) if loss_config is not None else None
+        self.quant_conv = nn.Conv2d(2 * dd_config["z_channels"], 2 * embedding_dim, 1)
         self.post_quant_conv = nn.Conv2d(embedding_dim, dd_config["z_channels"], 1)
         if monitor is not None:
             self.monitor = monitor
-        self._pq = None
+        self._pq = self._q = None
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=list(ignore_keys))
 
@@ -264,20 +367,30 @@ class AutoencoderKL(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         sd = {k.replace(".upsample.", ".up_sample."): v for k, v in state_dict.items()}
-        self._pq = None
+        self._pq = self._q = None
         self.decoder._pack = None
+        self.encoder._pack = None
         return super().load_state_dict(sd, strict=strict, **kw)
 
     def _apply(self, fn, *a, **kw):
-        self._pq = None
+        self._pq = self._q = None
         return super()._apply(fn, *a, **kw)
 
     def set_compute_dtype(self, dtype):
         self.decoder.set_compute_dtype(dtype)
-        self._pq = None
+        self.encoder.set_compute_dtype(dtype)
+        self._pq = self._q = None
 
+    @torch.no_grad()
     def encode(self, x):
-        raise NotImplementedError("AutoencoderKL.encode: the VAE encoder is outside the denoising hot path")
+        """Encoder then quant_conv (1x1) -> DiagonalGaussianDistribution over fp32 NCHW moments (restated: the
+        reference builds encoder + quant_conv, autoencoder.py:44-53, but has no encode method)."""
+        if self._q is None:
+            self._q = ops.pack_linear(self.quant_conv.weight, self.quant_conv.bias, dtype=self.encoder.compute_dtype)
+        h = self.encoder(x)                                            # [B, h, w, 2*z] 16-bit NHWC
+        b, hh, ww, c = h.shape
+        moments = ops.linear(h.reshape(b * hh * ww, c), self._q, out_nchw_f32=(b, hh, ww))
+        return DiagonalGaussianDistribution(moments)
 
     @torch.no_grad()
     def decode(self, z, scale=1.0):

@@ -196,6 +196,18 @@ def test_conv3x3(dev, b, h, w, cin, cout, stride, ups):
     assert rel_err(out.permute(0, 3, 1, 2), ref) < 6e-3
 
 
+@pytest.mark.parametrize("h,w", [(16, 16), (12, 20), (7, 9)])
+def test_conv3x3_asymmetric_pad(dev, h, w):
+    """VAE encoder DownSample: F.pad(x, (0, 1, 0, 1)) + conv3x3 stride 2 without padding (model.py:87,99-102)."""
+    ops = _ops()
+    x = rnd((2, 64, h, w), dev, 1)
+    wt, bias = rnd((96, 64, 3, 3), dev, 2, 1 / 24), rnd((96,), dev, 3)
+    out = ops.conv3x3(q(x).permute(0, 2, 3, 1).contiguous().to(BF16), ops.pack_conv3x3(wt, bias), stride=2, asym_pad=True)
+    ref = F.conv2d(F.pad(q(x), (0, 1, 0, 1)), q(wt), bias, stride=2, padding=0)
+    assert out.shape == (2, ref.shape[2], ref.shape[3], 96)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 6e-3
+
+
 def test_conv3x3_edges(dev):
     """conv_in (4 -> C, channels padded to 8), conv_out (C -> 4, fp32 NCHW out) and emb + residual epilogue."""
     ops = _ops()

@@ -396,3 +396,43 @@ def test_fp32_mode_ddim_steps_vs_oracle(dev):
         worst = max(worst, rel_err(out, torch.cat([e_uc, e_c])))
     print(f"[parity] ddim fp32 mode: teacher-forced worst per-step rel_err vs fp32 oracle {worst:.3e}")
     assert worst < FP32_GATE
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_tiny_encoder_vs_reference_golden(dev, dt):
+    """VAE Encoder (asymmetric-pad stride-2 DownSample, mid attention) and
+    DiagonalGaussianDistribution against what the reference's own code produced."""
+    from stablediffusion_amd.vae import Encoder, DiagonalGaussianDistribution
+    z = np.load(os.path.join(GOLD, "tiny_encoder.npz"))
+    enc, _ = build(Encoder, dict(synth.TINY_DDCONFIG, compute_dtype=TORCH_DT[dt]), "encoder.", dev)
+    m = enc(torch.from_numpy(z["x"]).to(dev))                     # NHWC 16-bit
+    assert m.shape == (2, 16, 16, 8)
+    e = rel_err(m.permute(0, 3, 1, 2), torch.from_numpy(z["moments"]))
+    print(f"[parity] tiny encoder ({dt}) vs reference golden: rel_err {e:.3e}")
+    assert e < TOL[dt]
+    g = DiagonalGaussianDistribution(torch.from_numpy(z["params"]).to(dev))
+    for name, t in (("mean", g.mean), ("log_var", g.log_var), ("std", g.std), ("var", g.var),
+                    ("sample", g.sample(torch.from_numpy(z["noise"]).to(dev)))):
+        np.testing.assert_allclose(t.cpu().numpy(), z[name], rtol=2e-6, atol=1e-7, err_msg=name)
+    assert torch.equal(g.mode(), g.mean)
+    det = DiagonalGaussianDistribution(torch.from_numpy(z["params"]).to(dev), deterministic=True)
+    assert float(det.std.abs().max()) == 0 and torch.equal(det.sample(), det.mean)
+
+
+def test_autoencoder_encode_decode_roundtrip_runs(dev):
+    """AutoencoderKL.encode -> LatentDiffusion.get_first_stage_encoding -> decode_first_stage: moments against the
+    oracle's vae_encode, shapes and scale factor through the img2img entry points."""
+    from oracle import model as OM
+    model, sd = _latent_diffusion(dev, policy(synth.TINY_UNET, "fp16"), synth.TINY_DDCONFIG)
+    vae_sd = {k[len("first_stage_model."):]: v for k, v in sd.items() if k.startswith("first_stage_model.")}
+    x = synth.synth_input("rt_img", (2, 3, 32, 32)).clamp(-1, 1)
+    post = model.encode_first_stage(x.to(dev))
+    with torch.no_grad():
+        ref = OM.vae_encode(vae_sd, synth.TINY_DDCONFIG, x)
+    e = rel_err(post.parameters, ref)
+    print(f"[parity] tiny AutoencoderKL.encode moments (fp16) vs oracle: rel_err {e:.3e}")
+    assert post.parameters.shape == (2, 8, 16, 16) and e < NORTH_STAR
+    zlat = model.get_first_stage_encoding(post, noise=torch.zeros(2, 4, 16, 16, device=dev))
+    assert torch.allclose(zlat, post.mean * float(model.scale_factor), rtol=1e-6, atol=1e-7)
+    img = model.decode_first_stage(zlat)
+    assert img.shape == (2, 3, 32, 32) and bool(torch.isfinite(img).all())

@@ -86,7 +86,9 @@ def load_reference():
     modules.Encoder, modules.Decoder = model.Encoder, model.Decoder
     openai = load("R.ldm.modules.diffusion.openai_model", "ldm/modules/diffusion/openai_model.py")
     ddim = load("R.ldm.models.diffusion.ddim", "ldm/models/diffusion/ddim.py")
-    return types.SimpleNamespace(utils=utils, attention=attention, util=util, model=model, openai=openai, ddim=ddim)
+    distribution = load("R.ldm.modules.distribution.distribution", "ldm/modules/distribution/distribution.py")
+    return types.SimpleNamespace(utils=utils, attention=attention, util=util, model=model, openai=openai, ddim=ddim,
+                                 distribution=distribution)
 
 
 def seed_module(m, prefix):
@@ -226,6 +228,40 @@ def gen_tables(ref):
     save("schedule_tables", **out)
 
 
+def build_ref_encoder(ref, dd):
+    kw = dict(dd)
+    kw["channels"] = kw.pop("ch")
+    kw["out_channels"] = kw.pop("out_ch")
+    orig_swish = ref.model.swish
+    ref.model.swish = lambda x: ref.model.group_norm(x) if isinstance(x, int) else orig_swish(x)   # B5, should it recur
+    try:
+        e = ref.model.Encoder(**kw)
+    finally:
+        ref.model.swish = orig_swish
+    return e.eval()
+
+
+@torch.no_grad()
+def gen_tiny_encoder(ref):
+    """the VAE Encoder (model.py:145-279) and DiagonalGaussianDistribution
+    (distribution.py:10-53) of the reference on the tiny config."""
+    e = build_ref_encoder(ref, synth.TINY_DDCONFIG)
+    seed_module(e, "encoder.")
+    x = synth.synth_input("tiny_img", (2, 3, 32, 32))
+    moments = e(x)
+    dist_mod = ref.distribution
+    params = synth.synth_input("tiny_moments", (2, 8, 4, 4), 12.0)      # wide range: exercises the log-var clamp
+    out = dict(x=x, moments=moments, keys=np.asarray(sorted(e.state_dict().keys())), params=params)
+    if dist_mod is not None:
+        g = dist_mod.DiagonalGaussianDistribution(params)
+        torch.manual_seed(123)
+        smp = g.sample()
+        torch.manual_seed(123)
+        noise = torch.randn_like(g.mean)
+        out.update(mean=g.mean, log_var=g.log_var, std=g.std, var=g.var, sample=smp, noise=noise)   # kl() is a stub (returns None)
+    save("tiny_encoder", **out)
+
+
 @torch.no_grad()
 def gen_tiny_composites(ref):
     cfg = dict(synth.TINY_UNET, use_fp16=False)     # fp32 reference path
@@ -280,5 +316,6 @@ if __name__ == "__main__":
     gen_leaves(reference)
     gen_tables(reference)
     gen_tiny_composites(reference)
+    gen_tiny_encoder(reference)
     if args.full:
         gen_full(reference)
