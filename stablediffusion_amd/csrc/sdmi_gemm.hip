@@ -133,10 +133,101 @@ __device__ __forceinline__ void wait_dma(int keep_stages) {
     else                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Fast 16-bit epilogue of one wave (row-major output, N % 8 == 0, column bias).  Two 16-column MFMA blocks that are
+// neighbours in N are exchanged between the lane rows with v_permlane16_swap, so a lane owns 8 consecutive output
+// columns of ONE block: stores (and residual loads) become 16 bytes per lane and 64 contiguous bytes per output row
+// instead of 8 and 32.  P0 = first block of the first pair, chosen by the caller so every pair starts on a 64-byte
+// boundary; blocks left over (TN odd) keep the 8-byte form.  All residual / embedding loads of a row block are
+// requested before the first one is consumed.
+template <int DT, int TN, int MI, int P0>
+__device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], int64_t mrow, int64_t ncol_w,
+                                                int fq, int64_t zoff_out, int64_t zoff_res) {
+    const int odd = fq & 1;
+    const int64_t ncol0 = ncol_w + 4 * fq;                  // own quad inside block 0
+    const int64_t ncol8 = ncol_w + odd * 16 + 4 * (fq & 2); // own 8 columns inside pair 0 (after the swap)
+    f32x4 bq[TN];
+    bool nval[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int64_t n = ncol0 + ni * 16;
+        nval[ni] = n < p.N;
+        bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
+    unsigned short* const outp = reinterpret_cast<unsigned short*>(p.out) + zoff_out;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int64_t m = mrow + mi * 16;
+        const bool mval = m < p.M;
+        uint2 rq[TN];
+        f32x4 eq[TN];
+        if (p.res != nullptr) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) rq[ni] = make_uint2(0u, 0u);
+#pragma unroll
+            for (int ni = P0; ni + 1 < TN; ni += 2) {
+                uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
+                const int64_t n = ncol8 + ni * 16;
+                if (mval && n < p.N) r4 = *reinterpret_cast<const uint4*>(resp + m * p.ld_res + n);
+                const auto sx = __builtin_amdgcn_permlane16_swap(r4.x, r4.z, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(r4.y, r4.w, false, false);
+                rq[ni] = make_uint2(sx[0], sy[0]);
+                rq[ni + 1] = make_uint2(sx[1], sy[1]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));
+                if (single && mval && nval[ni]) rq[ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);
+            }
+        }
+        if (p.emb != nullptr) {
+            const float* e = p.emb + (mval ? m / p.rows_per_batch : 0) * p.ld_emb;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                eq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (mval && nval[ni]) eq[ni] = *reinterpret_cast<const f32x4*>(e + ncol0 + ni * 16);
+            }
+        }
+        uint2 ov[TN];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            f32x4 v = acc[ni][mi] * p.alpha + bq[ni];
+            if (p.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+            }
+            if (p.emb != nullptr) v += eq[ni];
+            if (p.res != nullptr) {
+                float rf[4];
+                elem_unpack4<DT>(rq[ni], rf);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rf[j];
+            }
+            ov[ni].x = elem_pack2<DT>(v[0], v[1]);
+            ov[ni].y = elem_pack2<DT>(v[2], v[3]);
+        }
+#pragma unroll
+        for (int ni = P0; ni + 1 < TN; ni += 2) {
+            const auto sx = __builtin_amdgcn_permlane16_swap(ov[ni].x, ov[ni + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(ov[ni].y, ov[ni + 1].y, false, false);
+            const int64_t n = ncol8 + ni * 16;
+            if (mval && n < p.N) *reinterpret_cast<uint4*>(outp + m * p.ld_out + n) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));
+            if (single && mval && nval[ni]) *reinterpret_cast<uint2*>(outp + m * p.ld_out + ncol0 + ni * 16) = ov[ni];
+        }
+    }
+}
+
 // One workgroup = 8 waves (4 x 2), block tile (64*MI) x (32*TN) x 64, one workgroup per CU (two waves per SIMD),
 // 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
+// (the 2-stage variant: two workgroups per CU).  The second __launch_bounds__ argument is waves per SIMD in HIP, not
+// blocks per CU: 4 caps the 2-stage variant at 128 VGPRs so that two of its workgroups really fit.
 template <int MODE, int DT, int TN, int MI, int NST>
-__global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
+__global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
     constexpr int BM = 64 * MI;                 // 4 waves across M, MI 16-row blocks each
     constexpr int BN = TN * 32;                 // 2 waves across N, TN 16-column blocks each
     constexpr int A_CHUNKS = BM * (BK / 8);     // 16-byte chunks per A tile
@@ -431,6 +522,14 @@ __global__ __launch_bounds__(512, NST == 2 ? 2 : 1) void sdmi_gemm_kernel(const 
     // Common case (no GEGLU, row-major output, N % 4 == 0, column bias): all residual / embedding quads of a row
     // block are requested before the first one is consumed, so the loads overlap instead of forming one
     // load -> wait -> store round trip per quad.
+    if (!p.geglu && p.out_kind == 0 && (p.N & 7) == 0 && !p.bias_per_row && ((p.ld_out | p.ld_res) & 7) == 0 &&
+        (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)(2 * zoff_out) | (uintptr_t)(2 * zoff_res)) & 15) == 0) {
+        const int64_t mrow = m0 + wm * (MI * 16) + frow, ncol_w = n0 + wn * (TN * 16);
+        // pairs start on even 16-column blocks of the output: with 5 blocks per wave the odd wave column shifts by one
+        if ((TN & 1) && (wn & 1)) epilogue_rows16<DT, TN, MI, 1>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
+        else                      epilogue_rows16<DT, TN, MI, 0>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
+        return;
+    }
     if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row && !p.res_f32) {
         const int64_t ncol0 = n0 + wn * (TN * 16) + 4 * fq;
         f32x4 bq[TN];
