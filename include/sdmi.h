@@ -63,7 +63,7 @@ int sdmi_abi_version(void);
  *       Cin % 8 == 0; taps beyond 9 (K padding) read as zero.
  * Epilogue, in this order: *alpha, +bias (per column n, or per row m if bias_per_row),
  *   GEGLU (geglu=1: W rows hold [16 value | 16 gate] column blocks alternately, bias packed the
- *   same way; out = value * gelu_erf(gate); N counts gated output columns), act (1 = SiLU),
+ *   same way; out = value * gelu_erf(gate); N counts gated output columns), act (1 = SiLU, 2 = erf GELU),
  *   +emb[m / rows_per_batch, n] (fp32), +res[m, n] (16-bit), store as out_kind.
  *   out_kind 0: 16-bit [M, ld_out]; 1: fp32 [M, ld_out]; 2: fp32 NCHW [M/rows_per_batch, N, rows_per_batch].
  * batch > 1 runs `batch` independent problems (grid.z) with the element strides given.
@@ -201,6 +201,19 @@ int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float
                            void* stream);
 int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, void* stream);
 int sdmi_f32_timestep_embedding(const int64_t* t, float* out, int32_t nb, int32_t dim, float max_period, void* stream);
+
+/* Text conditioning stage (cond_stage_config, configs/stable-diffusion/v2-inference.yaml:63-67, called from
+ * LatentDiffusion.get_learned_conditioning, ldm/models/diffusion/ddpm.py:658-669).  The reference names
+ * FrozenOpenCLIPEmbedder but does not contain it; these are the two pieces of a pre-LN text transformer that the
+ * entry points above do not already cover.  fp32 like the rest of this section (the stage runs once per prompt).
+ *   embed_tokens : out[r, :] = table[ids[r], :] + pos[r % T, :]   (token_embedding + positional_embedding)
+ *   attention_d64_causal : sdmi_f32_attention_d64 with Nq == Nk == N and query i restricted to keys 0..i
+ *                          (the additive -inf upper-triangular attn_mask of the text tower)                      */
+int sdmi_f32_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* out, int64_t rows, int32_t T,
+                          int32_t C, int32_t vocab, void* stream);
+int sdmi_f32_attention_d64_causal(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
+                                  int32_t N, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                                  void* stream);
 
 /* DiagonalGaussianDistribution (ldm/modules/distribution/distribution.py:10-43) on fp32 NCHW moments
  * [nb, 2C, hw]: mean = first half, log_var = second half clamped to [-30, 20], std = exp(log_var / 2),

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_f32_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ out, int heads,
                                                       int Nq, int Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                                                      float scale) {
+                                                      float scale, int causal) {
     __shared__ float Ks[64][64], Vs[64][64];
     const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
     const int qi = blockIdx.x * 64 + threadIdx.x;
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
             Vs[r][d] = ok ? v[((int64_t)b * Nk + k0 + r) * ldv + h * 64 + d] : 0.f;
         }
         __syncthreads();
-        const int kn = Nk - k0 < 64 ? Nk - k0 : 64;
+        int kn = Nk - k0 < 64 ? Nk - k0 : 64;
+        if (causal && qi - k0 + 1 < kn) kn = qi - k0 + 1;       // query i attends to keys 0..i (per-thread bound)
         for (int j = 0; j < kn; ++j) {
             float s = 0.f;
 #pragma unroll
@@ -143,6 +144,24 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
         const float inv = 1.0f / l;
 #pragma unroll
         for (int d = 0; d < 64; ++d) op[d] = o[d] * inv;
+    }
+}
+
+// out[r, :] = table[ids[r], :] + pos[r % T, :]  (token + positional embedding of a text transformer).  An id outside
+// [0, vocab) is clamped: the host wrapper has already rejected it, this only keeps the access in bounds.
+__global__ __launch_bounds__(256) void embed_tokens_f32_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                               const float* __restrict__ pos, float* __restrict__ out,
+                                                               int64_t rows, int T, int C, int vocab) {
+    const int cq = C / 4;
+    const int64_t total = rows * cq;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cq;
+        const int c = (int)(idx - r * cq) * 4;
+        int64_t id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(table + id * C + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pos + (r % T) * C + c);
+        *reinterpret_cast<f32x4*>(out + r * C + c) = a + b;
     }
 }
 
@@ -213,16 +232,39 @@ extern "C" int sdmi_f32_layernorm(const float* x, const float* gamma, const floa
     return SDMI_OK;
 }
 
-extern "C" int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
+static int launch_attn_f32(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
                                       int32_t Nq, int32_t Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                                      float scale, void* stream) {
+                                      float scale, int causal, void* stream) {
     if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (nb <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return SDMI_ERR_BAD_ARG;
     if (ldq < (int64_t)heads * 64 || ldk < (int64_t)heads * 64 || ldv < (int64_t)heads * 64 || ldo < (int64_t)heads * 64)
         return SDMI_ERR_BAD_ARG;
     if ((int64_t)nb * heads > 65535) return SDMI_ERR_BAD_ARG;
     hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)((Nq + 63) / 64), (unsigned)(nb * heads)), dim3(64), 0,
-                       reinterpret_cast<hipStream_t>(stream), q, k, v, out, heads, Nq, Nk, ldq, ldk, ldv, ldo, scale);
+                       reinterpret_cast<hipStream_t>(stream), q, k, v, out, heads, Nq, Nk, ldq, ldk, ldv, ldo, scale,
+                       causal);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
+extern "C" int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
+                                      int32_t Nq, int32_t Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                      float scale, void* stream) {
+    return launch_attn_f32(q, k, v, out, nb, heads, Nq, Nk, ldq, ldk, ldv, ldo, scale, 0, stream);
+}
+
+extern "C" int sdmi_f32_attention_d64_causal(const float* q, const float* k, const float* v, float* out, int32_t nb,
+                                             int32_t heads, int32_t N, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                             float scale, void* stream) {
+    return launch_attn_f32(q, k, v, out, nb, heads, N, N, ldq, ldk, ldv, ldo, scale, 1, stream);
+}
+
+extern "C" int sdmi_f32_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* out, int64_t rows,
+                                     int32_t T, int32_t C, int32_t vocab, void* stream) {
+    if (ids == nullptr || table == nullptr || pos == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (rows <= 0 || T <= 0 || C <= 0 || vocab <= 0 || C % 4 != 0 || rows % T != 0) return SDMI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(embed_tokens_f32_kernel, dim3(blocks_for(rows * (C / 4))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), ids, table, pos, out, rows, T, C, vocab);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

@@ -69,6 +69,9 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
     if (p.act == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
+    } else if (p.act == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? gelu_erf_precise(v[j]) : gelu_erf_f(v[j]);
     }
     if (p.bias != nullptr && p.bias_per_row) {
         const float b = p.bias[m];
@@ -196,6 +199,9 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
             if (p.act == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
             }
             if (p.emb != nullptr) v += eq[ni];
             if (p.res != nullptr) {
@@ -571,6 +577,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 if (p.act == 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? gelu_erf_precise(v[j]) : gelu_erf_f(v[j]);
                 }
                 if (p.emb != nullptr) v += eq[ni];
                 if (p.res != nullptr) {
@@ -707,6 +716,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (a->K % BK != 0) return SDMI_ERR_ALIGNMENT;
     if (a->mode != 0 && a->mode != 1) return SDMI_ERR_BAD_ARG;
     if (a->out_kind < 0 || a->out_kind > 2) return SDMI_ERR_BAD_ARG;
+    if (a->act < 0 || a->act > 2) return SDMI_ERR_BAD_ARG;
     if (a->dtype != SDMI_DTYPE_BF16 && a->dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
     const int batch = a->batch > 0 ? a->batch : 1;
     const int split = a->split_k > 0 ? a->split_k : 1;

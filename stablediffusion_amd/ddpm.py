@@ -137,8 +137,8 @@ class LatentDiffusion(nn.Module):
             try:
                 model = instantiate_from_config(config)
             except (ImportError, ModuleNotFoundError, AttributeError) as e:
-                # e.g. ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder (yaml:63-67): absent from the
-                # reference and not downloadable offline - conditioning is then passed in as tensors.
+                # a cond stage this package does not provide (FrozenOpenCLIPEmbedder, yaml:63-67, is provided:
+                # encoders.py) - conditioning is then passed in as tensors.
                 print(f"[stablediffusion_amd] cond stage {config.get('target')} unavailable ({e}); "
                       f"pass [B, 77, context_dim] embeddings directly")
                 self.cond_stage_model = None
@@ -157,14 +157,18 @@ class LatentDiffusion(nn.Module):
         return self.load_state_dict(sd, strict=False)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        """Routes ``model.diffusion_model.*`` and ``first_stage_model.*`` through the sub-models' own
-        loaders so upstream key spellings are accepted (txt2img.py:46 uses strict=False)."""
+        """Routes ``model.diffusion_model.*``, ``first_stage_model.*`` and ``cond_stage_model.*`` through the
+        sub-models' own loaders so upstream key spellings are accepted (txt2img.py:46 uses strict=False)."""
         unet_sd = {k[len("model.diffusion_model."):]: v for k, v in state_dict.items()
                    if k.startswith("model.diffusion_model.")}
         vae_sd = {k[len("first_stage_model."):]: v for k, v in state_dict.items() if k.startswith("first_stage_model.")}
+        cond_sd = {k[len("cond_stage_model."):]: v for k, v in state_dict.items() if k.startswith("cond_stage_model.")}
         missing, unexpected = [], []
-        for prefix, sub, sd in (("model.diffusion_model.", self.model.diffusion_model, unet_sd),
-                                ("first_stage_model.", self.first_stage_model, vae_sd)):
+        subs = [("model.diffusion_model.", self.model.diffusion_model, unet_sd),
+                ("first_stage_model.", self.first_stage_model, vae_sd)]
+        if self.cond_stage_model is not None and self.cond_stage_model is not self.first_stage_model:
+            subs.append(("cond_stage_model.", self.cond_stage_model, cond_sd))       # the text tower (encoders.py)
+        for prefix, sub, sd in subs:
             if sd:
                 r = sub.load_state_dict(sd, strict=False)
                 missing += [prefix + k for k in r.missing_keys]
@@ -175,9 +179,9 @@ class LatentDiffusion(nn.Module):
 
     # -- the restated hot-path glue ------------------------------------------------------------
     def get_learned_conditioning(self, c):
+        if torch.is_tensor(c) and c.is_floating_point() and c.dim() == 3:
+            return c           # already an embedding [B, 77, context_dim]
         if self.cond_stage_model is None:
-            if torch.is_tensor(c):
-                return c       # already an embedding
             raise RuntimeError("no cond_stage_model: pass [B, 77, context_dim] text embeddings instead of prompts")
         enc = getattr(self.cond_stage_model, "encode", None)
         return enc(c) if callable(enc) else self.cond_stage_model(c)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "sdmi_f32_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
     "sdmi_f32_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
     "sdmi_f32_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
+    "sdmi_f32_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "sdmi_f32_attention_d64_causal": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
     "sdmi_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "sdmi_gemm_tile_m": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32]),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),

@@ -441,13 +441,21 @@ def layernorm(x, gamma, beta, eps=1e-5):
 # ----------------------------------------------------------------------------- attention
 
 
-def attention_d64(q, k, v, heads, nb, nq, nk, scale):
+def attention_d64(q, k, v, heads, nb, nq, nk, scale, causal=False):
     """q: [nb*nq, >=heads*64] (may be a column slice of a fused qkv buffer), k/v: [nb*nk, ...].
-    Row strides are taken from the tensors; the innermost stride must be 1."""
+    Row strides are taken from the tensors; the innermost stride must be 1.  causal (fp32, nq == nk): query i sees
+    keys 0..i - the text tower's attn_mask."""
     for t, name in ((q, "q"), (k, "k"), (v, "v")):
         if t.dtype != q.dtype or not t.is_cuda or t.stride(-1) != 1:
             raise hip.SdmiError(f"attention: bad {name}")
     out = torch.empty(nb * nq, heads * 64, dtype=q.dtype, device=q.device)
+    if causal:
+        if q.dtype != torch.float32 or nq != nk:
+            raise hip.SdmiError("attention: the causal form is fp32 self-attention only")
+        hip.check(hip.lib().sdmi_f32_attention_d64_causal(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, q.stride(0),
+                                                          k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+                  "sdmi_f32_attention_d64_causal")
+        return out
     if q.dtype == torch.float32:
         hip.check(hip.lib().sdmi_f32_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
                                                    v.stride(0), out.stride(0), scale, _stream()), "sdmi_f32_attention_d64")
@@ -455,6 +463,22 @@ def attention_d64(q, k, v, heads, nb, nq, nk, scale):
     dt = _dt(q.dtype)
     hip.check(hip.lib().sdmi_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
                                            v.stride(0), out.stride(0), scale, dt, _stream()), "sdmi_attention_d64")
+    return out
+
+
+def embed_tokens(ids, table, pos):
+    """ids int64 [B, T] -> fp32 [B, T, C] = table[ids] + pos  (token + positional embedding)."""
+    _require(table, torch.float32, "table")
+    _require(pos, torch.float32, "pos")
+    if ids.dtype != torch.int64 or not ids.is_cuda or not ids.is_contiguous() or ids.dim() != 2:
+        raise hip.SdmiError("embed_tokens: ids must be a contiguous device int64 [B, T] matrix")
+    b, t = ids.shape
+    vocab, c = table.shape
+    if pos.shape != (t, c):
+        raise hip.SdmiError(f"embed_tokens: positional table {tuple(pos.shape)} does not match [T={t}, C={c}]")
+    out = torch.empty(b, t, c, dtype=torch.float32, device=ids.device)
+    hip.check(hip.lib().sdmi_f32_embed_tokens(_p(ids), _p(table), _p(pos), _p(out), b * t, t, c, vocab, _stream()),
+              "sdmi_f32_embed_tokens")
     return out
 
 

@@ -9,7 +9,8 @@ Differences, all forced by the scope of the path:
     safetensors); upstream key spellings are renamed on load (unet.rename_upstream_keys);
   * the text encoder is out of scope (absent from the reference, weights not available offline): prompts are turned
     into conditioning by ``model.get_learned_conditioning`` when the config provides a cond stage, otherwise by
-    ``--cond_file`` (an .npz / .pt holding ``c`` [N, 77, context_dim] and optionally ``uc``) or, failing that, by a
+    ``--cond_file`` (an .npz / .pt holding ``c`` [N, 77, context_dim] and optionally ``uc``, or BPE token ids
+    ``tokens`` [N, 77] + ``uc_tokens`` [1, 77] for the text tower of ``encoders.py``) or, failing that, by a
     deterministic synthetic embedding seeded from the prompt string (announced on stdout - for smoke runs only);
   * ``--device`` must be cuda (the HIP path has no CPU fallback); ``--torchscript`` / ``--ipex`` are Intel-CPU
     paths of the reference and raise; ``--dpm`` raises (DPM-Solver is absent from the reference's samplers);
@@ -139,8 +140,15 @@ def _synthetic_embedding(prompt, n_tokens, dim):
 
 def _conditioning(model, prompts, cond_table, offset, context_dim, device):
     """(c, uc) for a batch of prompts: cond stage if the config gave one, else --cond_file rows, else synthetic."""
-    if model.cond_stage_model is not None:
+    if model.cond_stage_model is not None and getattr(model.cond_stage_model, "encodes_text", True):
         return model.get_learned_conditioning(list(prompts)), model.get_learned_conditioning(len(prompts) * [""])
+    if cond_table is not None and "tokens" in cond_table:
+        # token ids instead of embeddings: run them through the text tower (needs its weights from the checkpoint)
+        tok = cond_table["tokens"][offset:offset + len(prompts)].to(device)
+        if tok.shape[0] != len(prompts):
+            raise ValueError(f"--cond_file holds {cond_table['tokens'].shape[0]} token rows, need {offset + len(prompts)}")
+        utok = cond_table["uc_tokens"][:1].expand(len(prompts), -1).contiguous().to(device)
+        return model.get_learned_conditioning(tok), model.get_learned_conditioning(utok)
     if cond_table is not None:
         c = cond_table["c"][offset:offset + len(prompts)]
         if c.shape[0] != len(prompts):
@@ -196,8 +204,9 @@ def main(args):
     grid_count = len(os.listdir(args.out_dir)) - 1
     cond_table = _load_cond_file(args.cond_file)
     context_dim = config["model"]["params"]["unet_config"]["params"].get("context_dim", 1024)
-    if model.cond_stage_model is None and cond_table is None:
-        print("[txt2img] no text encoder and no --cond_file: using synthetic embeddings seeded from the prompt strings")
+    if cond_table is None and not getattr(model.cond_stage_model, "encodes_text", model.cond_stage_model is not None):
+        print("[txt2img] no text encoder that takes strings and no --cond_file: using synthetic embeddings seeded "
+              "from the prompt strings")
     shape = [args.channel, args.height // args.factor, args.width // args.factor]
     start_code = torch.randn([batch_size] + shape, device=device) if args.fixed_code else None
 

@@ -14,6 +14,7 @@ TARGET_ALIASES = {
     "ldm.modules.diffusionmodules.openaimodel.UNetModel": "stablediffusion_amd.unet.UNetModel",
     "ldm.modules.diffusion.openai_model.UNetModel": "stablediffusion_amd.unet.UNetModel",
     "ldm.models.autoencoder.AutoencoderKL": "stablediffusion_amd.vae.AutoencoderKL",
+    "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder": "stablediffusion_amd.encoders.FrozenOpenCLIPEmbedder",
 }
 
 

@@ -119,7 +119,7 @@ def _tiny_latent_diffusion():
             "embed_dim": 4, "ddconfig": dict(synth.TINY_DDCONFIG), "lossconfig": {"target": "torch.nn.Identity"}}},
         "cond_stage_config": {"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
                               "params": {"freeze": True, "layer": "penultimate"}}}}
-    return instantiate_from_config(cfg)
+    return instantiate_from_config(cfg)        # (the ViT-H text tower is built with uninitialised weights: free)
 
 
 def test_latent_diffusion_protocol_and_sampler_tables():
@@ -128,7 +128,16 @@ def test_latent_diffusion_protocol_and_sampler_tables():
     from stablediffusion_amd.plms import PLMSSampler
     model = _tiny_latent_diffusion()
     assert model.num_timesteps == 1000 and model.parameterization == "eps" and model.scale_factor == 0.18215
-    assert model.cond_stage_model is None          # OpenCLIP is absent offline: embeddings are passed in
+    from stablediffusion_amd.encoders import FrozenOpenCLIPEmbedder
+    te = model.cond_stage_model                    # yaml:63-67 names it; provided by encoders.py
+    assert isinstance(te, FrozenOpenCLIPEmbedder) and (te.width, te.heads, te.layers, te.layer_idx) == (1024, 16, 24, 1)
+    assert not te.weights_loaded and not te.encodes_text
+    emb = torch.zeros(2, 77, 1024)
+    assert model.get_learned_conditioning(emb) is emb          # ready embeddings pass through
+    with pytest.raises(RuntimeError, match="no BPE vocabulary"):
+        model.get_learned_conditioning(["a prompt"])
+    with pytest.raises(RuntimeError, match="no weights"):
+        model.get_learned_conditioning(torch.zeros(1, 77, dtype=torch.long))
     assert model.model.diffusion_model is not None and model.first_stage_model.decoder is not None
     assert model.alphas_cumprod.shape == (1000,) and torch.equal(model.alphas_bar, model.alphas_cumprod)
     assert abs(float(model.betas[0]) - 0.00085) < 1e-9 and abs(float(model.alphas_cumprod[999]) - 0.0046601) < 1e-6
@@ -288,7 +297,8 @@ def test_txt2img_surface(tmp_path):
         "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.TINY_UNET)},
         "first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL",
                                "params": {"embed_dim": 4, "ddconfig": dict(synth.TINY_DDCONFIG)}},
-        "cond_stage_config": {"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder", "params": {}}}}}
+        "cond_stage_config": {"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
+                              "params": {"width": 64, "heads": 1, "layers": 2, "vocab_size": 512}}}}}
     path = tmp_path / "tiny.yaml"
     path.write_text(yaml.safe_dump(cfg))
     assert txt2img.load_config(str(path)) == cfg

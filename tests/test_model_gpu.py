@@ -301,7 +301,8 @@ def test_txt2img_main_end_to_end(dev, tmp_path):
         "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.TINY_UNET)},
         "first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL",
                                "params": {"embed_dim": 4, "ddconfig": dict(synth.TINY_DDCONFIG)}},
-        "cond_stage_config": {"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder", "params": {}}}}}
+        "cond_stage_config": {"target": "ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
+                              "params": {"width": 64, "heads": 1, "layers": 2, "vocab_size": 512}}}}}
     (tmp_path / "tiny.yaml").write_text(yaml.safe_dump(cfg))
     grids = []
     for run, extra in enumerate(([], [], ["--plms", "--seed", "12"])):
