@@ -270,6 +270,34 @@ def test_unet_768_v_prediction_vs_oracle(dev):
     assert rel_err(y, ref) < NORTH_STAR
 
 
+def test_non_square_latents_vs_oracle(dev):
+    """--H / --W need not be equal (txt2img.py:147-158): a 40x24 latent (320x192 image) through the SD2 UNet and a
+    24x40 latent through the SD2 decoder - row counts that are not multiples of the 128/256-row tiles, attention
+    lengths 960 / 240 / 60 / 15 that are ragged against the 64-key tile - against the fp32 oracle, fp16 operands."""
+    from oracle import model as OM
+    from stablediffusion_amd.unet import UNetModel
+    from stablediffusion_amd.vae import AutoencoderKL
+    m, sd = build(UNetModel, policy(synth.SD2_UNET, "fp16"), "unet.", dev)
+    x = synth.synth_input("ns_x", (2, 4, 40, 24))
+    ctx = synth.synth_input("ns_ctx", (2, 77, 1024))
+    t = torch.tensor([17, 903])
+    y = m(x.to(dev), t.to(dev), ctx.to(dev))
+    with torch.no_grad():
+        ref = OM.unet_forward(sd, synth.SD2_UNET, x, t, ctx)
+    e = rel_err(y, ref)
+    print(f"[parity] sd2 unet 40x24 latent fp16: rel_err vs fp32 oracle {e:.3e}")
+    assert y.shape == (2, 4, 40, 24) and e < NORTH_STAR
+    vae, vsd = build(AutoencoderKL, dict(ddconfig=synth.SD2_DDCONFIG, embed_dim=4), "vae.", dev)
+    vae.set_compute_dtype(torch.float16)
+    z = synth.synth_input("ns_z", (1, 4, 24, 40))
+    img = vae.decode(z.to(dev), 1 / 0.18215)
+    with torch.no_grad():
+        ref = OM.vae_decode(vsd, synth.SD2_DDCONFIG, z / 0.18215)
+    e = rel_err(img, ref)
+    print(f"[parity] sd2 decoder 24x40 latent fp16: rel_err vs fp32 oracle {e:.3e}")
+    assert img.shape == (1, 3, 192, 320) and e < NORTH_STAR
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_decoder_768_batch_is_per_image(dev, dt):
     """BASELINE config 4 shape: decode_first_stage standalone at 768^2.  Size-independent property instead of a
