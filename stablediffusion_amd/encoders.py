@@ -15,9 +15,15 @@ with ``skip = 1`` for ``layer="penultimate"`` (what v2-inference.yaml asks for) 
 
 Runs on the HIP path only, in the package's fp32 mode (``ops`` fp32 entry points; every contraction on the bf16 MFMA
 GEMM through the exact three-piece split): the stage runs once per prompt, so exactness is worth more than speed.
-Not available offline and therefore not built: the BPE vocabulary (``open_clip.tokenize``) - ``encode`` takes token
-ids; ``wrap_token_ids`` adds start/end tokens and padding the way ``open_clip.tokenize`` does.
+The BPE vocabulary file (``bpe_simple_vocab_16e6.txt.gz``, shipped inside the ``open_clip`` / ``clip`` packages) is
+not available offline: ``encode`` takes token ids (``wrap_token_ids`` adds start/end tokens and padding the way
+``open_clip.tokenize`` does), and takes strings only when ``bpe_path`` (or ``$SDMI_BPE_VOCAB``) names that file -
+``SimpleTokenizer`` below is the published byte-level BPE of CLIP, minus the optional ``ftfy`` text repair.
 """
+import gzip
+import html
+import os
+
 import torch
 import torch.nn as nn
 
@@ -39,6 +45,78 @@ def wrap_token_ids(id_lists, context_length=77, sot=SOT_TOKEN, eot=EOT_TOKEN):
             toks[-1] = eot
         out[i, :len(toks)] = torch.tensor(toks, dtype=torch.long)
     return out
+
+
+def _bytes_to_unicode():
+    """The reversible byte -> printable unicode character table of GPT-2 / CLIP byte-level BPE."""
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, (chr(c) for c in cs)))
+
+
+class SimpleTokenizer:
+    """CLIP's tokenizer: lower-cased, whitespace-normalised text is cut into words by a fixed pattern, every word is
+    spelled in byte characters with an end-of-word mark and merged greedily by the rank of the merge list in
+    ``bpe_path`` (gzip or plain text: a header line, then one ``left right`` merge per line).  Vocabulary order:
+    256 byte characters, the same with ``</w>``, the merges, ``<start_of_text>``, ``<end_of_text>``."""
+
+    def __init__(self, bpe_path, n_merges=49152 - 256 - 2):
+        import regex
+        opener = gzip.open if bpe_path.endswith(".gz") else open
+        with opener(bpe_path, "rt", encoding="utf-8") as fh:
+            lines = fh.read().split("\n")
+        merges = [tuple(m.split()) for m in lines[1:n_merges + 1] if len(m.split()) == 2]
+        self.byte_encoder = _bytes_to_unicode()
+        vocab = list(self.byte_encoder.values())
+        vocab = vocab + [v + "</w>" for v in vocab] + ["".join(m) for m in merges] + ["<start_of_text>", "<end_of_text>"]
+        self.encoder = {tok: i for i, tok in enumerate(vocab)}
+        self.bpe_ranks = {m: i for i, m in enumerate(merges)}
+        self.cache = {"<start_of_text>": "<start_of_text>", "<end_of_text>": "<end_of_text>"}
+        self.pat = regex.compile(r"""<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""",
+                                 regex.IGNORECASE)
+        self.sot, self.eot = self.encoder["<start_of_text>"], self.encoder["<end_of_text>"]
+
+    def bpe(self, token):
+        if token in self.cache:
+            return self.cache[token]
+        word = tuple(token[:-1]) + (token[-1] + "</w>",)
+        while len(word) > 1:
+            pairs = set(zip(word[:-1], word[1:]))
+            best = min(pairs, key=lambda pr: self.bpe_ranks.get(pr, float("inf")))
+            if best not in self.bpe_ranks:
+                break
+            first, second = best
+            merged, i = [], 0
+            while i < len(word):
+                if i + 1 < len(word) and word[i] == first and word[i + 1] == second:
+                    merged.append(first + second)
+                    i += 2
+                else:
+                    merged.append(word[i])
+                    i += 1
+            word = tuple(merged)
+        out = " ".join(word)
+        self.cache[token] = out
+        return out
+
+    def encode(self, text):
+        text = " ".join(html.unescape(html.unescape(text)).split()).strip().lower()
+        ids = []
+        for token in self.pat.findall(text):
+            token = "".join(self.byte_encoder[b] for b in token.encode("utf-8"))
+            ids.extend(self.encoder[t] for t in self.bpe(token).split(" "))
+        return ids
+
+    def __call__(self, texts, context_length=77):
+        if isinstance(texts, str):
+            texts = [texts]
+        return wrap_token_ids([self.encode(t) for t in texts], context_length, self.sot, self.eot)
 
 
 class _Affine(nn.Module):
@@ -98,10 +176,9 @@ class FrozenOpenCLIPEmbedder(nn.Module):
     ``layers``, ``vocab_size`` override the arch table (tests use a small tower).  The modules below only hold the
     parameters: ``forward`` runs the HIP entry points and raises without the library or a GPU."""
     LAYERS = ["last", "penultimate"]
-    encodes_text = False        # no BPE vocabulary offline: token ids in, not strings (txt2img falls back accordingly)
 
     def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", device="cuda", max_length=77, freeze=True,
-                 layer="last", width=None, heads=None, layers=None, vocab_size=49408, mlp_ratio=4):
+                 layer="last", width=None, heads=None, layers=None, vocab_size=49408, mlp_ratio=4, bpe_path=None):
         super().__init__()
         if layer not in self.LAYERS:
             raise NotImplementedError(f"layer={layer!r}: expected one of {self.LAYERS}")
@@ -118,6 +195,10 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         self.model = _TextTower(vocab_size, max_length, self.width, self.layers, mlp_ratio * self.width)
         self.weights_loaded = False
         self._pack = None
+        # strings are accepted only with the BPE vocabulary file (not available offline); txt2img falls back otherwise
+        bpe_path = bpe_path or os.environ.get("SDMI_BPE_VOCAB")
+        self.tokenizer = SimpleTokenizer(bpe_path, vocab_size - 256 - 256 - 2) if bpe_path else None
+        self.encodes_text = self.tokenizer is not None
         if freeze:
             self.freeze()
 
@@ -216,8 +297,11 @@ class FrozenOpenCLIPEmbedder(nn.Module):
     def forward(self, text):
         if torch.is_tensor(text):
             return self.encode_with_transformer(text)
-        raise RuntimeError("FrozenOpenCLIPEmbedder: no BPE vocabulary offline (open_clip.tokenize is unavailable); pass "
-                           "int64 [B, 77] token ids (encoders.wrap_token_ids) or ready [B, 77, C] embeddings")
+        if self.tokenizer is None:
+            raise RuntimeError("FrozenOpenCLIPEmbedder: no BPE vocabulary (bpe_path / $SDMI_BPE_VOCAB; the file ships with "
+                               "open_clip, which is unavailable offline); pass int64 [B, 77] token ids "
+                               "(encoders.wrap_token_ids) or ready [B, 77, C] embeddings")
+        return self.encode_with_transformer(self.tokenizer(text, self.max_length).to(torch.device("cuda")))
 
     def encode(self, text):
         return self(text)

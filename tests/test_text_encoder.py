@@ -94,6 +94,28 @@ def test_embedder_surface_cpu():
         fresh(torch.zeros(1, 77, dtype=torch.long))
 
 
+def test_bpe_tokenizer_on_a_synthetic_vocabulary(tmp_path):
+    """The real merge list ships with open_clip (absent): a two-merge vocabulary with hand-computed ids exercises
+    the algorithm - byte spelling, end-of-word mark, greedy merges by rank, lower-casing, start/end/padding."""
+    import gzip
+    from stablediffusion_amd.encoders import SimpleTokenizer, FrozenOpenCLIPEmbedder
+    path = tmp_path / "bpe.txt.gz"
+    with gzip.open(path, "wt", encoding="utf-8") as fh:
+        fh.write("#version: synthetic\nl o\nlo w</w>\n")
+    tok = SimpleTokenizer(str(path), n_merges=2)
+    # vocabulary: 256 byte characters ('!' first), 256 with </w>, "lo" = 512, "low</w>" = 513, <sot> = 514, <eot> = 515
+    assert (tok.sot, tok.eot) == (514, 515)
+    assert tok.encode("low") == [513] and tok.encode("Low   LOW") == [513, 513]
+    assert tok.encode("lower") == [512, ord("w") - 33, ord("e") - 33, 256 + ord("r") - 33]
+    # a word that ends in "o": the end-of-word mark makes it a different symbol, so ("l", "o") does not apply
+    assert tok.encode("lo!") == [ord("l") - 33, 256 + ord("o") - 33, 256 + 0]
+    assert tok.encode("l&amp;amp;o") == tok.encode("l&o") == [256 + ord("l") - 33, 256 + ord("&") - 33, 256 + ord("o") - 33]
+    t = tok(["low", "low low"])
+    assert t.shape == (2, 77) and t[0].tolist()[:4] == [514, 513, 515, 0] and t[1].tolist()[:5] == [514, 513, 513, 515, 0]
+    m = FrozenOpenCLIPEmbedder(width=64, heads=1, layers=1, vocab_size=516, bpe_path=str(path))
+    assert m.encodes_text and m.tokenizer.encode("low") == [513]
+
+
 # ----------------------------------------------------------------------------- GPU
 
 gpu = pytest.mark.gpu
