@@ -613,9 +613,33 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 bg[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
             }
         }
+        // 16-bit output with nothing else to add: the wave's two output blocks (pi = 0, 1: 32 adjacent columns) are
+        // paired through v_permlane16_swap as in epilogue_rows16 - 16-byte stores, 64 contiguous bytes per row
+        const bool wide = TN == 4 && p.out_kind == 0 && p.res == nullptr && p.emb == nullptr && !p.bias_per_row &&
+                          (p.N & 31) == 0 && (p.ld_out & 7) == 0 &&
+                          (((uintptr_t)p.out | (uintptr_t)(2 * zoff_out)) & 15) == 0;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
+            if (wide) {
+                uint2 ov[TN / 2];
+#pragma unroll
+                for (int pi = 0; pi < TN / 2; ++pi) {
+                    f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+                    ov[pi].x = elem_pack2<DT>(v[0], v[1]);
+                    ov[pi].y = elem_pack2<DT>(v[2], v[3]);
+                }
+                const auto sx = __builtin_amdgcn_permlane16_swap(ov[0].x, ov[TN / 2 - 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(ov[0].y, ov[TN / 2 - 1].y, false, false);
+                // N % 32 == 0: the wave's 32 output columns are inside N or outside it as a whole
+                const int64_t n = ((n0 + wn * (TN * 16)) >> 1) + (fq & 1) * 16 + 4 * (fq & 2);
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n) =
+                        make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                continue;
+            }
             if (m >= p.M) continue;
 #pragma unroll
             for (int pi = 0; pi < TN / 2; ++pi) {

@@ -98,6 +98,16 @@ def test_geglu(dev):
     ref = a * F.gelu(gate)
     assert out.shape == (m, 4 * c)
     assert rel_err(out, ref) < 1e-4
+    # 16-bit output: the paired 16-byte store form of the epilogue (fast erf instead of erff: a rounding boundary may
+    # fall differently, nothing more)
+    out16 = ops.linear(x.to(BF16), ops.pack_geglu(w, b))
+    assert out16.dtype == BF16 and rel_err(out16.float(), out) < 5e-3
+    assert float((out16 != out.to(BF16)).float().mean()) < 1e-3
+    # ... and with an output width that is not a multiple of 32 (falls back to the quad stores)
+    w3, b3 = rnd((2 * 80, c), dev, 4, c ** -0.5), rnd((2 * 80,), dev, 5)
+    a3, g3 = F.linear(q(x), q(w3), b3).chunk(2, dim=-1)
+    o3 = ops.linear(x.to(BF16), ops.pack_geglu(w3, b3))
+    assert o3.shape == (m, 80) and rel_err(o3.float(), a3 * F.gelu(g3)) < 1e-2
 
 
 def test_split_k(dev):
