@@ -39,7 +39,7 @@ typedef enum sdmi_status {
 typedef enum sdmi_dtype { SDMI_DTYPE_BF16 = 0, SDMI_DTYPE_F16 = 1 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);
+int sdmi_abi_version(void);   /* 3: + sdmi_f32_embed_tokens, sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2 (2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM convolution on 16-bit (bf16 | f16) MFMA, fp32 accumulate:

@@ -12,4 +12,4 @@ extern "C" const char* sdmi_status_str(int status) {
     }
 }
 
-extern "C" int sdmi_abi_version(void) { return 2; }
+extern "C" int sdmi_abi_version(void) { return 3; }
