@@ -43,6 +43,8 @@ class GemmArgs(C.Structure):
     ]
 
 
+ABI_VERSION = 3     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/sdmi.h declares
@@ -93,6 +95,9 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if handle.sdmi_abi_version() != ABI_VERSION:
+            raise SdmiError(f"{LIB_PATH} has ABI version {handle.sdmi_abi_version()}, this package expects "
+                            f"{ABI_VERSION} (GemmArgs layout, entry points): rebuild with `make -C stablediffusion_amd/csrc`")
         _lib = handle
     return _lib
 
