@@ -247,6 +247,8 @@ class FrozenOpenCLIPEmbedder(nn.Module):
 
     def _apply(self, fn, *a, **kw):
         self._pack = None
+        if not self.weights_loaded:
+            return self         # uninitialised storage: moving or casting it would only touch 1.4 GB for nothing
         return super()._apply(fn, *a, **kw)
 
     def _build_pack(self, dev):
