@@ -52,7 +52,16 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lr = lane & 31, hf = lane >> 5;
-    const int bh = blockIdx.y;
+    // XCD-aware placement: workgroups are dealt to the 8 XCDs round-robin by linear id, so the query blocks of one
+    // (batch, head) - which all read the same K/V - would land on all eight L2s.  Remap the linear id so that they
+    // share one XCD (K/V of the ~3 heads resident per XCD stay in its 4 MiB L2).
+    int qblk = blockIdx.x, bh = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {           // (a bijection only when batch x heads is a multiple of 8)
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, k = lin >> 3;
+        bh = (k / (int)gridDim.x) * 8 + xcd;
+        qblk = k % (int)gridDim.x;
+    }
     const int b = bh / p.heads, h = bh - b * p.heads;
 
     const unsigned short* Qp = p.q + (int64_t)b * p.Nq * p.ldq + h * D;
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     unsigned short* Op = p.out + (int64_t)b * p.Nq * p.ldo + h * D;
 
     // Q fragments (B operand of S^T = K Q^T): lane (q = lr, half hf), k-step s: Q[q][16s + 8hf .. +7]
-    const int qrow = blockIdx.x * QB + wid * 32 + lr;
+    const int qrow = qblk * QB + wid * 32 + lr;
     const int qrow_c = qrow < p.Nq ? qrow : p.Nq - 1;
     uint4 qf[4];
 #pragma unroll
