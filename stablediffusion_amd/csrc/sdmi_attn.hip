@@ -56,11 +56,14 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     // (batch, head) - which all read the same K/V - would land on all eight L2s.  Remap the linear id so that they
     // share one XCD (K/V of the ~3 heads resident per XCD stay in its 4 MiB L2).
     int qblk = blockIdx.x, bh = blockIdx.y;
-    if ((gridDim.y & 7) == 0) {           // (a bijection only when batch x heads is a multiple of 8)
+    {
+        // heads are taken eight at a time (a bijection on every full group of 8; a tail of < 8 heads keeps its ids)
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int xcd = lin & 7, k = lin >> 3;
-        bh = (k / (int)gridDim.x) * 8 + xcd;
-        qblk = k % (int)gridDim.x;
+        if (lin < (int)((gridDim.y & ~7u) * gridDim.x)) {
+            const int xcd = lin & 7, k = lin >> 3;
+            bh = (k / (int)gridDim.x) * 8 + xcd;
+            qblk = k % (int)gridDim.x;
+        }
     }
     const int b = bh / p.heads, h = bh - b * p.heads;
 

@@ -303,7 +303,8 @@ def _attn_ref(qq, kk, vv, nb, heads, nq, nk, scale):
 
 
 @pytest.mark.parametrize("nb,heads,nq,nk", [(2, 5, 1024, 1024), (2, 20, 64, 64), (2, 10, 256, 77), (1, 3, 16, 16),
-                                            (1, 2, 144, 144), (1, 5, 4096, 77), (1, 1, 200, 333)])
+                                            (1, 2, 144, 144), (1, 5, 4096, 77), (1, 1, 200, 333), (3, 3, 300, 200),
+                                            (4, 4, 130, 64)])
 def test_attention(dev, nb, heads, nq, nk):
     ops = _ops()
     c = heads * 64
