@@ -26,21 +26,23 @@ sys.path.insert(0, ROOT)
 SD2_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
                 num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64, use_spatial_transformer=True,
                 use_linear_in_transformer=True, transformer_depth=1, context_dim=1024, legacy=False,
-                use_checkpoint=True, use_bf16=True)
+                use_checkpoint=True)      # + use_fp16 / use_bf16 from --dtype (v2-inference.yaml:24 ships use_fp16: True)
 SD2_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
                     ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 # algorithmic FLOPs (2 per MAC), SURVEY.md §8(d) / BASELINE.md §4
 UNET_GFLOP = {32: 181.1, 64: 804.3, 96: 2149.1}
 DEC_GFLOP = {32: 622.2, 64: 2514.5, 96: 5754.3}
-MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 / fp16 (same rate), MI355X_MICROARCH.md
+HBM_PEAK_TBS = 8.0            # HBM3E spec (6.3 TB/s measured achievable), MI355X_MICROARCH.md
 
 
-def build_model(dev, parameterization="eps"):
+def build_model(dev, parameterization="eps", dtype="fp16"):
     from stablediffusion_amd import instantiate_from_config
     cfg = {"target": "ldm.models.diffusion.ddpm.LatentDiffusion", "params": {
         "linear_start": 0.00085, "linear_end": 0.0120, "timesteps": 1000, "conditioning_key": "crossattn",
         "scale_factor": 0.18215, "use_ema": False, "parameterization": parameterization, "image_size": 64, "channels": 4,
-        "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(SD2_UNET)},
+        "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                        "params": dict(SD2_UNET, use_fp16=dtype == "fp16", use_bf16=dtype == "bf16")},
         "first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL", "params": {
             "embed_dim": 4, "ddconfig": dict(SD2_DDCONFIG), "lossconfig": {"target": "torch.nn.Identity"}}},
         "cond_stage_config": "__is_unconditional__", "force_null_conditioning": True}}
@@ -65,10 +67,12 @@ def build_model(dev, parameterization="eps"):
     return model.eval()
 
 
-def cpu_baseline(model, h, ddim_steps):
-    """The oracle (CPU fp32 restatement, oracle/) timed on this box's host cores on a bounded sample of the
-    same workload: two CFG UNet steps (batch 2) at the benchmark latent size + one 1-image decode, scaled to
-    images/sec = 1 / (ddim_steps * t_step + t_decode)."""
+def cpu_baseline(model, h, ddim_steps, scale):
+    """The oracle (CPU fp32 restatement, oracle/) timed on this box's host cores, as BASELINE.md §3 plans:
+    (i) BASELINE.json configs[0] run IN FULL - 256^2 (32x32 latent), batch 1, 10 DDIM steps with CFG (20 UNet-sample
+    forwards) + 1 decode - reported as config0_*; (ii) one CFG UNet step (batch 2) at the benchmark latent size + one
+    1-image decode at the benchmark image size, scaled to the metric's unit as 1 / (ddim_steps * t_step + t_decode)
+    = `value` (the same workload per image as the GPU line's)."""
     from oracle import model as OM
     from oracle import sampler as OS
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
@@ -76,30 +80,43 @@ def cpu_baseline(model, h, ddim_steps):
     usd = {k: v.detach().float().cpu() for k, v in model.model.diffusion_model.state_dict().items()}
     vsd = {k: v.detach().float().cpu() for k, v in model.first_stage_model.state_dict().items()}
     cfg = {k: v for k, v in SD2_UNET.items()}
-    x = torch.randn(2, 4, h, h)
-    ctx = torch.randn(2, 77, 1024)
-    t = torch.full((2,), 501, dtype=torch.long)
+    acp = model.alphas_cumprod.cpu().numpy()
+    g = torch.Generator().manual_seed(1234)
     with torch.no_grad():
-        OM.unet_forward(usd, cfg, x[:1, :, :16, :16].contiguous(), t[:1], ctx[:1])     # page in / warm up
+        OM.unet_forward(usd, cfg, torch.randn(1, 4, 16, 16, generator=g), torch.tensor([501]), torch.randn(1, 77, 1024, generator=g))  # page in
+        # (i) configs[0] in full
+        x_T = torch.randn(1, 4, 32, 32, generator=g)
+        c, uc = torch.randn(1, 77, 1024, generator=g), torch.randn(1, 77, 1024, generator=g)
         t0 = time.perf_counter()
-        n_steps = 2
-        for _ in range(n_steps):
-            OM.unet_forward(usd, cfg, x, t, ctx)
-        t_step = (time.perf_counter() - t0) / n_steps
+        fn = lambda x, t, cond: OS.apply_model(usd, cfg, x, t, cond)
+        lat = OS.ddim_sample(fn, acp, 10, x_T, c, uc, scale, 0.0, getattr(model, "parameterization", "eps"))
+        t_loop = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        OS.decode_first_stage(vsd, SD2_DDCONFIG, lat, 0.18215)
+        t_dec0 = time.perf_counter() - t0
+        # (ii) one step + one decode at the benchmark size
+        x = torch.randn(2, 4, h, h, generator=g)
+        ctx = torch.randn(2, 77, 1024, generator=g)
+        t = torch.full((2,), 501, dtype=torch.long)
+        t0 = time.perf_counter()
+        OM.unet_forward(usd, cfg, x, t, ctx)
+        t_step = time.perf_counter() - t0
         t0 = time.perf_counter()
         OS.decode_first_stage(vsd, SD2_DDCONFIG, x[:1], 0.18215)
         t_dec = time.perf_counter() - t0
     return {"value": 1.0 / (ddim_steps * t_step + t_dec), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{n_steps} CFG UNet steps (batch 2, {h}x{h} latent) + 1 VAE decode ({8 * h}^2) of the fp32 CPU "
-                      f"oracle; scaled as 1/({ddim_steps}*t_step + t_decode)",
+            "sample": f"fp32 CPU oracle: BASELINE configs[0] in full (256^2, batch 1, 10 DDIM steps + CFG + decode: "
+                      f"{t_loop + t_dec0:.1f} s/image) + 1 CFG UNet step (batch 2, {h}x{h} latent) + 1 VAE decode "
+                      f"({8 * h}^2); value = 1/({ddim_steps}*t_step + t_decode), the GPU line's per-image workload",
+            "config0_s_per_image": t_loop + t_dec0, "config0_images_per_sec": 1.0 / (t_loop + t_dec0),
             "unet_step_s": t_step, "decode_s": t_dec}
 
 
-def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T):
-    """Dominant kernel = sdmi_gemm_kernel<1> (implicit-GEMM conv3x3, 52% of UNet and 99% of decoder FLOPs).
-    achieved = algorithmic FLOPs per launch / average launch duration, both averaged over the launch
-    population of ONE benchmark step (ddim_steps UNet forwards at batch 2B + one decode of B images);
-    durations from HIP events recorded on the launch stream around every launch."""
+def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype):
+    """Per kernel family of ONE benchmark step (ddim_steps UNet forwards at batch 2B + one decode of B images):
+    algorithmic work (FLOPs for conv / linear / attention, bytes = one read + one write for GroupNorm / LayerNorm,
+    SURVEY.md §8(d)) / launch durations from HIP events recorded on the launch stream around every launch.
+    The top-level object is the family that takes the most GPU time; `families` carries all of them."""
     from stablediffusion_amd import ops
     dev = x_T.device
     c_in = torch.cat([uc, c]).contiguous()
@@ -117,7 +134,7 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T):
     un = collect(lambda: model.apply_model(x_in, ts, c_in))
     de = collect(lambda: model.decode_first_stage(x_T))
     out = {}
-    for kind in ("conv3x3", "linear"):
+    for kind in ("conv3x3", "linear", "attention", "groupnorm", "layernorm"):
         u = [(f, t) for k, f, t, _, _ in un if k == kind]
         d = [(f, t) for k, f, t, _, _ in de if k == kind]
         fl = ddim_steps * sum(f for f, _ in u) + sum(f for f, _ in d)
@@ -128,30 +145,77 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T):
         agg = {}
         for src, lst in (("unet", un), ("dec", de)):
             for k, f, t, sk, shp in lst:
-                e = agg.setdefault((src, k) + shp + (sk,), [0, 0.0, 0.0])
+                e = agg.setdefault((src, k) + tuple(shp) + (sk,), [0, 0.0, 0.0])
                 e[0] += 1; e[1] += t; e[2] += f
         with open(os.environ["SDMI_DUMP_SHAPES"], "w") as fh:
-            fh.write("src kind M N K stride ups splitk calls total_us TFLOPs\n")
+            fh.write("src kind shape... splitk calls total_us T(FLOP|B)/s\n")
             for key, (n_, t_, f_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                fh.write(" ".join(str(x) for x in key) + f" {n_} {t_ * 1e6:.1f} {f_ / t_ / 1e12:.1f}\n")
-    fl, tm, n = out["conv3x3"]
-    lf, lt, ln = out["linear"]
-    # HBM-side bytes per conv launch: PMC figures of a separate rocprofv3 run of this same command, committed
-    # under profiles/ (counters cannot be read from inside the process); null when the file is absent
-    traffic = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+                fh.write(" ".join(str(x) for x in key) + f" {n_} {t_ * 1e6:.1f} {f_ / t_ / 1e12:.2f}\n")
+    names = {"conv3x3": "sdmi_gemm_kernel<1,...> (implicit-GEMM conv3x3, MFMA 16x16x32)",
+             "linear": "sdmi_gemm_kernel<0,...> (linear / conv1x1, MFMA 16x16x32)",
+             "attention": "attn_fwd_d64_kernel (flash attention d=64, MFMA 32x32x16)",
+             "groupnorm": "gn_stats_kernel + gn_apply_kernel (GroupNorm(32)+SiLU)", "layernorm": "layernorm_kernel"}
+    t_all = sum(v[1] for v in out.values())
+    fam = {}
+    for kind, (w, tm, n) in out.items():
+        if n == 0:
+            continue
+        mfma = kind in ("conv3x3", "linear", "attention")
+        ach = w / tm / 1e12
+        fam[kind] = {"kernel": names[kind], "bound": "mfma" if mfma else "hbm", "achieved": ach,
+                     "peak": MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_TBS, "unit": "TFLOP/s" if mfma else "TB/s",
+                     "frac": ach / (MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_TBS), "work_per_launch": w / n,
+                     "avg_launch_us": tm / n * 1e6, "launches_per_step": n, "time_share": tm / t_all}
+    dom = max(fam, key=lambda k: fam[k]["time_share"])
+    # HBM-side bytes per launch of each family: PMC figures of separate rocprofv3 passes over this same command,
+    # committed under profiles/ (counters cannot be read from inside the process); null when the file is absent
+    traffic, tnote = None, "no profiles/r02_traffic.json"
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as fh:
-            traffic = json.load(fh)["per_launch_kib"]["conv"]["bytes_per_launch"]
-    return {"bound": "mfma", "achieved": fl / tm / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": fl / tm / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_note": "L2-miss bytes per conv launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json); "
-                            "the kernel is MFMA-bound, the figure shows it stays far below the HBM bound",
-            "kernel": "sdmi_gemm_kernel<1> (implicit-GEMM conv3x3, bf16 MFMA 16x16x32)",
-            "flops_per_launch": fl / n, "avg_launch_us": tm / n * 1e6, "launches_per_step": n,
-            "note": "launch time includes the split-K reduce kernel where split-K is used",
-            "linear_kernel": {"kernel": "sdmi_gemm_kernel<0>", "achieved": lf / lt / 1e12, "frac": lf / lt / 1e12 / MFMA_PEAK_TFLOPS,
-                              "flops_per_launch": lf / ln, "avg_launch_us": lt / ln * 1e6, "launches_per_step": ln}}
+            tj = json.load(fh)
+        for kind in fam:
+            e = tj.get("per_family", {}).get(kind)
+            if e:
+                fam[kind]["traffic"] = e["bytes_per_launch"]
+        traffic = fam[dom].get("traffic")
+        tnote = tj.get("note", "")
+    top = dict(fam[dom])
+    top.update({"traffic": traffic, "traffic_note": tnote, "dtype": dtype, "families": fam,
+                "note": "time-dominant kernel family of the step; durations are HIP-event brackets around each launch "
+                        "(split-K reduce launches and the event-to-event gap included); mfma fractions against the "
+                        "2.5 PFLOP/s dense 16-bit peak, hbm fractions against the 8 TB/s spec"})
+    return top
+
+
+def secondary_dtype(model, dt, x_in, ts, c_in, x_T, ddim_steps, B):
+    """The other 16-bit operand policy on the same weights (informational line beside the headline): UNet step and
+    decode times, and the images/sec they imply."""
+    unet, vae = model.model.diffusion_model, model.first_stage_model
+    prev = unet.compute_dtype
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    unet.dtype = unet.compute_dtype = tdt
+    unet.invalidate_packed()
+    vae.set_compute_dtype(tdt)
+    try:
+        model.apply_model(x_in, ts, c_in)
+        model.decode_first_stage(x_T)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(5):
+            model.apply_model(x_in, ts, c_in)
+        e1.record()
+        model.decode_first_stage(x_T)
+        e2.record()
+        torch.cuda.synchronize()
+        step, dec = e0.elapsed_time(e1) / 5, e1.elapsed_time(e2)
+    finally:
+        unet.dtype = unet.compute_dtype = prev
+        unet.invalidate_packed()
+        vae.set_compute_dtype(prev)
+    return {"dtype": dt, "unet_step_ms": step, "decode_ms": dec,
+            "images_per_sec_from_step_and_decode": B / ((ddim_steps * step + dec) * 1e-3),
+            "note": "same MFMA rate as the headline dtype; parity of this policy: tests/test_model_gpu.py docstring"}
 
 
 def main():
@@ -169,6 +233,10 @@ def main():
     ap.add_argument("--hip-graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the UNet step from a captured hipGraph (auto: when batch <= 2, where the step is launch-bound)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the BASELINE configs[1] (batch 1) latency leg")
+    ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16",
+                    help="MFMA operand / storage type (the reference's use_fp16 / use_bf16 policy).  fp16 is the headline: "
+                         "it is what v2-inference.yaml ships and it meets the 1e-2 parity gate; bf16 runs at the same rate")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary-dtype (bf16) UNet-step / decode timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,7 +252,7 @@ def main():
 
     from stablediffusion_amd.ddim import DDIMSampler
     from stablediffusion_amd import ops
-    model = build_model(dev, args.parameterization)
+    model = build_model(dev, args.parameterization, args.dtype)
     B, h = args.batch, args.latent
     use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and B <= 2)
     sampler = DDIMSampler(model, hip_graph=use_graph)
@@ -230,7 +298,7 @@ def main():
     result = {
         "metric": "images/sec (node) SD2-base 512^2 50-step DDIM; UNet step ms", "value": value, "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"SD2 v2-inference UNet+VAE random-init, {8 * h}^2 ({h}x{h} latent), batch {B}/GPU, "
                                f"{args.ddim_steps} DDIM steps + CFG (UNet batch {2 * B}), decode + uint8; "
                                f"BASELINE.json configs[{1 if B == 1 else 2}]",
@@ -292,9 +360,12 @@ def main():
 
     if rank == 0:
         if not args.no_roofline:
-            result["roofline"] = roofline(model, sampler, B, h, args.ddim_steps, c, uc, x_T)
+            result["roofline"] = roofline(model, sampler, B, h, args.ddim_steps, c, uc, x_T, args.dtype)
+        if world == 1 and not args.no_secondary:
+            result["secondary_dtype"] = secondary_dtype(model, "bf16" if args.dtype == "fp16" else "fp16", x_in, ts, c_in, x_T,
+                                                        args.ddim_steps, B)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(model, h, args.ddim_steps)
+            result["cpu_baseline"] = cpu_baseline(model, h, args.ddim_steps, args.scale)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

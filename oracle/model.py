@@ -39,6 +39,27 @@ def _q(x):
     return x if OPERAND_DTYPE is None else x.to(OPERAND_DTYPE).to(x.dtype)
 
 
+# Storage-precision emulation (precision studies only; None = off).  The HIP path keeps the residual stream - the
+# tensors that are not operands of the next contraction but inputs of a norm or of a later residual add - in a 16-bit
+# type; `storage_precision(dtype)` rounds exactly those points (UNet only) so that the cost of that choice can be
+# separated from the operand format's.
+STORAGE_DTYPE = None
+
+
+class storage_precision(operand_precision):
+    def __enter__(self):
+        global STORAGE_DTYPE
+        self.prev, STORAGE_DTYPE = STORAGE_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global STORAGE_DTYPE
+        STORAGE_DTYPE = self.prev
+
+
+def _s(x):
+    return x if STORAGE_DTYPE is None else x.to(STORAGE_DTYPE).to(x.dtype)
+
+
 
 def _get(sd, *names):
     for n in names:
@@ -84,11 +105,11 @@ def res_block(sd, p, x, emb):
     """ResBlock._forward, openai_model.py:262-304 (plain branch: no up/down, no scale-shift)."""
     h = _conv(sd, p + "in_layers.2.", F.silu(_gn(sd, p + "in_layers.0.", x, 1e-5)))
     e = _lin(sd, _pfx(sd, p, "embedding_layers.1.", "emb_layers.1."), F.silu(emb)).type(h.dtype)
-    h = h + e[:, :, None, None]
+    h = _s(h + e[:, :, None, None])
     h = _conv(sd, p + "out_layers.3.", F.silu(_gn(sd, p + "out_layers.0.", h, 1e-5)))
     if p + "skip_connection.weight" in sd:       # openai_model.py:241-248
-        x = _conv(sd, p + "skip_connection.", x)
-    return x + h
+        x = _s(_conv(sd, p + "skip_connection.", x))
+    return _s(x + h)
 
 
 def _pfx(sd, p, *alts):
@@ -130,9 +151,9 @@ def basic_transformer_block(sd, p, x, context, heads):
     def ln(name, t):
         return F.layer_norm(t, (t.shape[-1],), sd[p + name + ".weight"], sd[p + name + ".bias"], 1e-5)
 
-    x = cross_attention(sd, p + "attn1.", ln("norm1", x), None, heads) + x
-    x = cross_attention(sd, p + "attn2.", ln("norm2", x), context, heads) + x
-    x = feed_forward(sd, ff, ln("norm3", x)) + x
+    x = _s(cross_attention(sd, p + "attn1.", ln("norm1", x), None, heads) + x)
+    x = _s(cross_attention(sd, p + "attn2.", ln("norm2", x), context, heads) + x)
+    x = _s(feed_forward(sd, ff, ln("norm3", x)) + x)
     return x
 
 
@@ -149,6 +170,7 @@ def spatial_transformer(sd, p, x, context, heads):
     x = x.permute(0, 2, 3, 1).reshape(b, h * w, -1)
     if use_linear:
         x = _lin(sd, pin, x)
+    x = _s(x)
     d = 0
     while _has(sd, f"{p}transformer_blocks.{d}.norm1.weight"):
         x = basic_transformer_block(sd, f"{p}transformer_blocks.{d}.", x, context, heads)
@@ -158,17 +180,17 @@ def spatial_transformer(sd, p, x, context, heads):
     x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2)
     if not use_linear:
         x = _conv(sd, p + "proj_out.", x)
-    return x + x_in
+    return _s(x + x_in)
 
 
 def down_sample(sd, p, x):
     """DownSample (use_conv=True), openai_model.py:119-148: conv3x3 stride 2 pad 1."""
-    return _conv(sd, _pfx(sd, p, "operation.", "op."), x, stride=2)
+    return _s(_conv(sd, _pfx(sd, p, "operation.", "op."), x, stride=2))
 
 
 def up_sample(sd, p, x):
     """UpSample, openai_model.py:67-116: nearest x2 then conv3x3."""
-    return _conv(sd, p + "conv.", F.interpolate(x, scale_factor=2, mode="nearest"))
+    return _s(_conv(sd, p + "conv.", F.interpolate(x, scale_factor=2, mode="nearest")))
 
 
 def unet_layout(cfg):
@@ -223,7 +245,7 @@ def _run_block(sd, p, layers, h, emb, context):
         q = f"{p}{j}."
         kind = layer[0]
         if kind == "conv":
-            h = _conv(sd, q, h)
+            h = _s(_conv(sd, q, h))
         elif kind == "res":
             h = res_block(sd, q, h, emb)
         elif kind == "st":

@@ -1,681 +1,26 @@
-// sdmi_gemm: bf16 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+// sdmi_gemm: 16-bit (bf16 | f16) MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
 //
 //   out[m, n] = epilogue(alpha * sum_k A[m, k] * W[n, k])          (see include/sdmi.h)
 //
-// One kernel serves nn.Linear, conv1x1 and conv3x3 (stride 1/2, optional fused nearest-x2
-// gather, optional two-pointer channel concat): they differ only in how a 128-row x 64-k tile
-// of A is gathered from HBM.  Both operands are K-contiguous, so both MFMA fragments are plain
-// 16-byte LDS reads.
+// One kernel template (sdmi_gemm_kernel.h) serves nn.Linear, conv1x1 and conv3x3 (stride 1/2, optional fused
+// nearest-x2 gather, optional two-pointer channel concat): the modes differ only in how a tile of A is gathered.
+// Both operands are K-contiguous, so both MFMA fragments are plain 16-byte LDS reads.
 //
-// Tiling: 128(M) x 128(N) x 64(K) per 256-thread workgroup; 4 waves as 2x2, each wave a 64x64
-// sub-tile = 4x4 MFMA 16x16x32 tiles (64 fp32 accumulators).  The MFMA "A" operand is the W
-// tile and the "B" operand is the activation tile, so an accumulator register quad holds 4
-// CONSECUTIVE output columns of one output row: epilogue loads/stores are 8-16 byte vectors.
-// LDS: double-buffered A and W tiles, 64 KiB, XOR-swizzled 16-byte chunks (conflict-free
-// ds_read_b128), filled by global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip, no ds_write -
-// the ds_write_b128 path alone would cost ~0.8 of the MFMA time of a tile).  The gather of the
-// implicit GEMM is expressed in the per-lane SOURCE address (zero taps read a zero constant);
-// the DMA of tile k+1 is issued before the MFMAs of tile k and retired at the barrier.
-// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous, group-M-swizzled
-// range of tiles.
-#include "sdmi_common.h"
-
-#ifndef SDMI_SCHED_INTERLEAVE
-#define SDMI_SCHED_INTERLEAVE 1   // A/B: +1..3% on MI355X
-#endif
-#ifndef SDMI_SETPRIO
-#define SDMI_SETPRIO 0   // A/B on MI355X (tools/ab_build.sh): raising the wave priority around the MFMA groups gains nothing here
-#endif
+// Tiling: 8 waves (4 x 2) per workgroup, block tile (64*MI) x (32*TN) x 64 with MI in {4, 2} (256 | 128 rows) and
+// TN in {5, 4} (160 | 128 columns); a wave owns MI x TN v_mfma_f32_16x16x32 accumulators.  The MFMA "A" operand is
+// the W tile and the "B" operand the activation tile, so an accumulator quad holds 4 CONSECUTIVE output columns of
+// one output row: epilogue loads / stores are 8-16 byte vectors.
+// LDS: 3-stage ring (2 stages for the short-K variant that runs two workgroups per CU) of XOR-swizzled 16-byte
+// chunks (conflict-free ds_read_b128), filled by global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip, no
+// ds_write) and retired with counted s_waitcnt vmcnt(N), one barrier per k-tile, half-tile software pipeline.
+// The gather of the implicit GEMM is expressed in the per-lane SOURCE address (zero taps read a zero constant).
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous, group-M-swizzled range of tiles.
+// This file: the split-K reduce kernel and the C entry point; the kernel template is instantiated per
+// (mode, dtype) in sdmi_gemm_m?_*.hip so that the units compile in parallel.
+#include <mutex>
+#include "sdmi_gemm_kernel.h"
 
 namespace {
-
-// Zeros: the DMA source of out-of-image conv taps and padded rows / columns (the DMA cannot mask).  Long enough
-// that a tap's pointer can walk a whole channel run (Cin <= ZERO_ELEMS) without leaving it.
-constexpr int ZERO_ELEMS = 16384;
-__device__ const uint4 sdmi_zeros[ZERO_ELEMS / 8 + 1] = {};
-
-// Block tile BM x BN x BK with BN = 32*TN: TN = 4 (128 columns) or TN = 5 (160 columns; every UNet width is a
-// multiple of 160, so those layers lose nothing to column padding).
-// and BM = 64*MI: MI = 4 (256 rows) or MI = 2 (128 rows); 8 waves, 3-stage ring, one block per CU.
-constexpr int BK = 64;
-constexpr int lds_bytes(int tn, int mi, int nst) { return nst * (mi * 64 + tn * 32) * (BK / 8) * 16; }
-constexpr int GROUP_M = 8;
-
-struct TileCoord { int tm, tn; };
-
-__device__ __forceinline__ TileCoord tile_of_block(int bid, int tiles_m, int tiles_n) {
-    const int nwg = tiles_m * tiles_n;
-    // XCD-aware bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous range.
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    // group-M swizzle inside the range
-    const int per_group = GROUP_M * tiles_n;
-    const int g = lid / per_group;
-    const int first_m = g * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int in_g = lid - g * per_group;
-    TileCoord t;
-    t.tm = first_m + in_g % gsz;
-    t.tn = in_g / gsz;
-    return t;
-}
-
-// Epilogue for 4 consecutive output columns of one row.  `v` is the raw accumulator quad (already
-// scaled and biased by the caller for the column-bias / GEGLU cases).
-template <int DT>
-__device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, int64_t n, f32x4 v,
-                                           int64_t zoff_out, int64_t zoff_res) {
-    if (p.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
-    } else if (p.act == 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? gelu_erf_precise(v[j]) : gelu_erf_f(v[j]);
-    }
-    if (p.bias != nullptr && p.bias_per_row) {
-        const float b = p.bias[m];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += b;
-    }
-    const bool full = (n + 3 < p.N);
-    if (p.emb != nullptr) {
-        const float* e = p.emb + (m / p.rows_per_batch) * p.ld_emb + n;
-        if (full) {
-            const f32x4 ev = *reinterpret_cast<const f32x4*>(e);
-            v += ev;
-        } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += e[j];
-        }
-    }
-    if (p.res != nullptr && p.res_f32) {
-        const float* r = reinterpret_cast<const float*>(p.res) + zoff_res + m * p.ld_res + n;
-        for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += r[j];
-    } else if (p.res != nullptr) {
-        const unsigned short* r = reinterpret_cast<const unsigned short*>(p.res) + zoff_res + m * p.ld_res + n;
-        if (full) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(r);
-            float rf[4];
-            elem_unpack4<DT>(rv, rf);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += rf[j];
-        } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += elem_to_f32<DT>(r[j]);
-        }
-    }
-    if (p.out_kind == 0) {
-        unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n;
-        if (full) {
-            uint2 ov;
-            ov.x = elem_pack2<DT>(v[0], v[1]);
-            ov.y = elem_pack2<DT>(v[2], v[3]);
-            *reinterpret_cast<uint2*>(o) = ov;
-        } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = elem_from_f32<DT>(v[j]);
-        }
-    } else if (p.out_kind == 1) {
-        float* o = reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n;
-        if (full) {
-            *reinterpret_cast<f32x4*>(o) = v;
-        } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = v[j];
-        }
-    } else {  // fp32 NCHW
-        const int64_t b = m / p.rows_per_batch, pix = m - b * p.rows_per_batch;
-        float* o = reinterpret_cast<float*>(p.out) + zoff_out + (b * p.N + n) * p.rows_per_batch + pix;
-        for (int j = 0; j < 4 && n + j < p.N; ++j) o[j * p.rows_per_batch] = v[j];
-    }
-}
-
-// Wait until at most `keep_stages` (0, 1, 2) of this wave's youngest ring stages (PER LDS-DMA instructions each)
-// are still in flight.
-template <int PER>
-__device__ __forceinline__ void wait_dma(int keep_stages) {
-    if (keep_stages >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER) : "memory");
-    else if (keep_stages == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
-    else                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// Fast 16-bit epilogue of one wave (row-major output, N % 8 == 0, column bias).  Two 16-column MFMA blocks that are
-// neighbours in N are exchanged between the lane rows with v_permlane16_swap, so a lane owns 8 consecutive output
-// columns of ONE block: stores (and residual loads) become 16 bytes per lane and 64 contiguous bytes per output row
-// instead of 8 and 32.  P0 = first block of the first pair, chosen by the caller so every pair starts on a 64-byte
-// boundary; blocks left over (TN odd) keep the 8-byte form.  All residual / embedding loads of a row block are
-// requested before the first one is consumed.
-template <int DT, int TN, int MI, int P0>
-__device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], int64_t mrow, int64_t ncol_w,
-                                                int fq, int64_t zoff_out, int64_t zoff_res) {
-    const int odd = fq & 1;
-    const int64_t ncol0 = ncol_w + 4 * fq;                  // own quad inside block 0
-    const int64_t ncol8 = ncol_w + odd * 16 + 4 * (fq & 2); // own 8 columns inside pair 0 (after the swap)
-    f32x4 bq[TN];
-    bool nval[TN];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int64_t n = ncol0 + ni * 16;
-        nval[ni] = n < p.N;
-        bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
-    }
-    const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
-    unsigned short* const outp = reinterpret_cast<unsigned short*>(p.out) + zoff_out;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int64_t m = mrow + mi * 16;
-        const bool mval = m < p.M;
-        uint2 rq[TN];
-        f32x4 eq[TN];
-        if (p.res != nullptr) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) rq[ni] = make_uint2(0u, 0u);
-#pragma unroll
-            for (int ni = P0; ni + 1 < TN; ni += 2) {
-                uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
-                const int64_t n = ncol8 + ni * 16;
-                if (mval && n < p.N) r4 = *reinterpret_cast<const uint4*>(resp + m * p.ld_res + n);
-                const auto sx = __builtin_amdgcn_permlane16_swap(r4.x, r4.z, false, false);
-                const auto sy = __builtin_amdgcn_permlane16_swap(r4.y, r4.w, false, false);
-                rq[ni] = make_uint2(sx[0], sy[0]);
-                rq[ni + 1] = make_uint2(sx[1], sy[1]);
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));
-                if (single && mval && nval[ni]) rq[ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);
-            }
-        }
-        if (p.emb != nullptr) {
-            const float* e = p.emb + (mval ? m / p.rows_per_batch : 0) * p.ld_emb;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                eq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (mval && nval[ni]) eq[ni] = *reinterpret_cast<const f32x4*>(e + ncol0 + ni * 16);
-            }
-        }
-        uint2 ov[TN];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            f32x4 v = acc[ni][mi] * p.alpha + bq[ni];
-            if (p.act == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-            } else if (p.act == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
-            }
-            if (p.emb != nullptr) v += eq[ni];
-            if (p.res != nullptr) {
-                float rf[4];
-                elem_unpack4<DT>(rq[ni], rf);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += rf[j];
-            }
-            ov[ni].x = elem_pack2<DT>(v[0], v[1]);
-            ov[ni].y = elem_pack2<DT>(v[2], v[3]);
-        }
-#pragma unroll
-        for (int ni = P0; ni + 1 < TN; ni += 2) {
-            const auto sx = __builtin_amdgcn_permlane16_swap(ov[ni].x, ov[ni + 1].x, false, false);
-            const auto sy = __builtin_amdgcn_permlane16_swap(ov[ni].y, ov[ni + 1].y, false, false);
-            const int64_t n = ncol8 + ni * 16;
-            if (mval && n < p.N) *reinterpret_cast<uint4*>(outp + m * p.ld_out + n) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));
-            if (single && mval && nval[ni]) *reinterpret_cast<uint2*>(outp + m * p.ld_out + ncol0 + ni * 16) = ov[ni];
-        }
-    }
-}
-
-// One workgroup = 8 waves (4 x 2), block tile (64*MI) x (32*TN) x 64, one workgroup per CU (two waves per SIMD),
-// 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
-// (the 2-stage variant: two workgroups per CU).  The second __launch_bounds__ argument is waves per SIMD in HIP, not
-// blocks per CU: 4 caps the 2-stage variant at 128 VGPRs so that two of its workgroups really fit.
-template <int MODE, int DT, int TN, int MI, int NST>
-__global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
-    constexpr int BM = 64 * MI;                 // 4 waves across M, MI 16-row blocks each
-    constexpr int BN = TN * 32;                 // 2 waves across N, TN 16-column blocks each
-    constexpr int A_CHUNKS = BM * (BK / 8);     // 16-byte chunks per A tile
-    constexpr int W_CHUNKS = BN * (BK / 8);     // 16-byte chunks per W tile
-    constexpr int STAGE_CHUNKS = A_CHUNKS + W_CHUNKS;
-    constexpr int RPI = 64;                     // tile rows one DMA instruction of the whole block covers
-    constexpr int NA = BM / RPI;                // A instructions per thread and stage (4 | 2)
-    constexpr int NW = BN / RPI;                // W instructions every thread issues (2)
-    constexpr bool W_TAIL = (BN % RPI) != 0;    // leftover 32 W rows (TN = 5): waves 0..3 issue one more
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint4* const lds = reinterpret_cast<const uint4*>(smem);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-
-    const int64_t n_w = p.geglu ? 2 * p.N : p.N;          // weight rows in use
-    const int tiles_m = (int)((p.M + BM - 1) / BM);
-    const int tiles_n = (int)((n_w + BN - 1) / BN);
-    const TileCoord tc = tile_of_block(blockIdx.x, tiles_m, tiles_n);
-    const int64_t m0 = (int64_t)tc.tm * BM;
-    const int64_t n0 = (int64_t)tc.tn * BN;
-
-    // grid.z is either the batch index or the split-K slice
-    const int z = blockIdx.z;
-    const int nk_total = (int)(p.K / BK);
-    int kt_begin = 0, kt_end = nk_total;
-    int64_t zoff_a = 0, zoff_w = 0, zoff_out = 0, zoff_res = 0;
-    if (p.split_k > 1) {
-        const int per = (nk_total + p.split_k - 1) / p.split_k;
-        kt_begin = z * per;
-        kt_end = min(nk_total, kt_begin + per);
-    } else {
-        zoff_a = z * p.stride_a; zoff_w = z * p.stride_w; zoff_out = z * p.stride_out; zoff_res = z * p.stride_res;
-    }
-
-    const unsigned short* const A = reinterpret_cast<const unsigned short*>(p.A) + zoff_a;
-    const unsigned short* const A2 = reinterpret_cast<const unsigned short*>(p.A2);
-    const unsigned short* const W = reinterpret_cast<const unsigned short*>(p.W) + zoff_w;
-
-    // ---- loader geometry: thread owns 16-byte chunk `lc` of rows lr + 64*i ----
-    // A wave-instruction writes LDS at (wave-uniform base) + lane*16, i.e. 8 consecutive tile rows x 8 physical
-    // chunks.  The XOR swizzle therefore goes on the SOURCE address: lane l owns physical chunk l&7 of row
-    // 64*i + 8*wave + (l>>3) and fetches logical chunk (l&7) ^ (row&7).
-    const int lr = tid >> 3;                    // tile rows lr + 64*i
-    const int lc = (tid & 7) ^ (lr & 7);        // LOGICAL 16-byte chunk fetched into physical chunk tid&7
-    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
-    const bool w_tail_wave = W_TAIL && wave_u < (BN - NW * RPI) / 8;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned d_wave = lds_base + wave_u * 1024;
-    const unsigned short* const zsrc = reinterpret_cast<const unsigned short*>(sdmi_zeros);
-    const int64_t k_valid = p.k_valid > 0 ? p.k_valid : p.K;
-
-    // W: scalar base (tile row n0, k-tile) + constant per-lane byte offsets
-    const unsigned short* const w_tile = W + n0 * p.K;
-    unsigned w_voff[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) w_voff[i] = (unsigned)((((int64_t)lr + RPI * i) * p.K + lc * 8) * 2);
-
-    // A, mode 0: scalar base (tile row m0, k-tile) + constant per-lane byte offsets; rows past M re-read row M-1
-    // (their results are never stored).  A k-tile that crosses k_valid takes the general path below.
-    unsigned a_voff[NA], a2_voff[NA];
-    // A, general path and conv
-    int64_t a_off[NA];      // MODE 0: row m;  MODE 1: pixel base b*H*W
-    int iy0[NA], ix0[NA];   // MODE 1
-    bool rvalid[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int64_t m = m0 + lr + RPI * i;
-        rvalid[i] = m < p.M;
-        if (MODE == 0) {
-            a_off[i] = m;
-            const int64_t rrel = (rvalid[i] ? m : p.M - 1) - m0;
-            a_voff[i] = (unsigned)((rrel * p.lda + lc * 8) * 2);
-            a2_voff[i] = (unsigned)((rrel * p.lda2 + lc * 8) * 2);
-        } else {
-            const int64_t hw = (int64_t)p.Ho * p.Wo;
-            const int64_t b = m / hw;
-            const int rem = (int)(m - b * hw);
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_off[i] = b * (int64_t)p.H * p.W_in;
-            const int pad_lo = p.asym_pad ? 0 : 1;          // asym_pad: zero pad on the bottom / right only
-            iy0[i] = rvalid[i] ? oy * p.stride - pad_lo : -(1 << 20);
-            ix0[i] = ox * p.stride - pad_lo;
-        }
-    }
-    const int Hl = p.H << p.upsample, Wl = p.W_in << p.upsample;
-    // Conv with Cin % 64 == 0: a k-tile never straddles a tap, so (tap, channel run) is one scalar state per wave
-    // and each row keeps a 64-bit pointer that is rebuilt when the tap changes and bumped by 64 channels otherwise.
-    const bool conv_fast = MODE == 1 && (p.Cin % BK) == 0 && p.Cin <= ZERO_ELEMS;
-    int f_tap = 0, f_ci = 0;
-    bool f_new_tap = true;
-    const unsigned short* a_ptr[NA];
-    // general conv path: per-lane (tap, ci) of this thread's chunk, k = kt*64 + lc*8
-    int c_tap = 0, c_ci = 0;
-    if (MODE == 1) {
-        f_tap = (kt_begin * BK) / p.Cin;
-        f_ci = kt_begin * BK - f_tap * p.Cin;
-        const int k = kt_begin * BK + lc * 8;
-        c_tap = k / p.Cin;
-        c_ci = k - c_tap * p.Cin;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) a_ptr[i] = zsrc;
-    }
-
-    // general path: one load per statement, 64-bit pointer, zero source where masked
-#define SDMI_GLDS(SRC, D0, OFF)                                                                            \
-    do {                                                                                                   \
-        unsigned keep_;                                                                                    \
-        const void* src_ = (SRC);                                                                          \
-        const unsigned dst_ = (D0) + (OFF);                                                                \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                              \
-                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                                 \
-                     : "=&s"(keep_) : "v"(src_), "s"(dst_) : "memory");                                    \
-    } while (0)
-#define SDMI_STAGE_A0(I, KK, BASE, LD, D0)                                                                 \
-    SDMI_GLDS((rvalid[I] && kin_) ? (BASE) + a_off[I] * (LD) + (KK) : zsrc, D0, 8192 * (I))
-#define SDMI_STAGE_A1(I, KY, KX, TV, D0)                                                                   \
-    do {                                                                                                   \
-        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                      \
-        const bool ok_ = (TV) && (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;             \
-        iy_ >>= p.upsample; ix_ >>= p.upsample;                                                            \
-        const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin + c_ci;                      \
-        SDMI_GLDS(ok_ ? A + off_ : zsrc, D0, 8192 * (I));                                                  \
-    } while (0)
-#define SDMI_TAP_PTR(I, KY, KX)                                                                            \
-    do {                                                                                                   \
-        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                      \
-        const bool ok_ = (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;                     \
-        iy_ >>= p.upsample; ix_ >>= p.upsample;                                                            \
-        const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin;                             \
-        a_ptr[I] = (ok_ ? A + off_ : zsrc) + (f_ci + lc * 8);                                              \
-    } while (0)
-
-    // Issue this wave's share of the DMA of k-tile KT into ring stage BUF (A tile first, W tile behind it).
-#define SDMI_STAGE_TILE(KT, BUF)                                                                           \
-    do {                                                                                                   \
-        const unsigned d0_ = d_wave + (BUF) * (STAGE_CHUNKS * 16);                                         \
-        const int64_t k0_ = (int64_t)(KT) * BK;                                                            \
-        if (MODE == 0) {                                                                                   \
-            if (k0_ + BK <= k_valid) {                                                                     \
-                const bool second_ = (A2 != nullptr) && (k0_ >= p.k_split);                                \
-                const unsigned short* sa_ = second_ ? A2 + m0 * p.lda2 + (k0_ - p.k_split) : A + m0 * p.lda + k0_; \
-                if (NA == 4)                                                                               \
-                    glds_s4<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[1] : a_voff[1], \
-                               second_ ? a2_voff[NA - 2] : a_voff[NA - 2], second_ ? a2_voff[NA - 1] : a_voff[NA - 1]); \
-                else                                                                                       \
-                    glds_s2<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[1] : a_voff[1]); \
-            } else {                                                                                       \
-                const int64_t k_ = k0_ + lc * 8;                                                           \
-                const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */   \
-                const bool second_ = (A2 != nullptr) && (k_ >= p.k_split);                                 \
-                const unsigned short* base_ = second_ ? A2 : A;                                            \
-                const int64_t ld_ = second_ ? p.lda2 : p.lda;                                              \
-                const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                         \
-                SDMI_STAGE_A0(0, kk_, base_, ld_, d0_); SDMI_STAGE_A0(1, kk_, base_, ld_, d0_);            \
-                if (NA == 4) { SDMI_STAGE_A0(NA - 2, kk_, base_, ld_, d0_); SDMI_STAGE_A0(NA - 1, kk_, base_, ld_, d0_); } \
-            }                                                                                              \
-        } else if (conv_fast) {                                                                            \
-            if (f_new_tap) {                                                                               \
-                const int ky_ = f_tap / 3, kx_ = f_tap - 3 * ky_;                                          \
-                SDMI_TAP_PTR(0, ky_, kx_); SDMI_TAP_PTR(1, ky_, kx_);                                      \
-                if (NA == 4) { SDMI_TAP_PTR(NA - 2, ky_, kx_); SDMI_TAP_PTR(NA - 1, ky_, kx_); }           \
-            }                                                                                              \
-            if (NA == 4) glds_v4<0>(d0_, a_ptr[0], a_ptr[1], a_ptr[NA - 2], a_ptr[NA - 1]);                \
-            else         glds_v2<0>(d0_, a_ptr[0], a_ptr[1]);                                              \
-            _Pragma("unroll")                                                                              \
-            for (int i_ = 0; i_ < NA; ++i_) a_ptr[i_] += BK;                                               \
-            f_ci += BK;                                                                                    \
-            f_new_tap = f_ci == p.Cin;                                                                     \
-            if (f_new_tap) { f_ci = 0; ++f_tap; }                                                          \
-        } else {                                                                                           \
-            const int ky_ = c_tap / 3, kx_ = c_tap - 3 * ky_;                                              \
-            const bool tapvalid_ = c_tap < 9;                                                              \
-            SDMI_STAGE_A1(0, ky_, kx_, tapvalid_, d0_); SDMI_STAGE_A1(1, ky_, kx_, tapvalid_, d0_);        \
-            if (NA == 4) { SDMI_STAGE_A1(NA - 2, ky_, kx_, tapvalid_, d0_); SDMI_STAGE_A1(NA - 1, ky_, kx_, tapvalid_, d0_); } \
-            c_ci += BK;                                                                                    \
-            while (c_ci >= p.Cin) { c_ci -= p.Cin; ++c_tap; }                                              \
-        }                                                                                                  \
-        if (w_tail_wave) glds_s3<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1], w_voff[2]);       \
-        else             glds_s2<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1]);                  \
-    } while (0)
-#define SDMI_WAIT_DMA(KEEP)                                                                                \
-    do {                                                                                                   \
-        if (w_tail_wave) wait_dma<NA + NW + 1>(KEEP); else wait_dma<NA + NW>(KEEP);                        \
-    } while (0)
-
-    f32x4 acc[TN][MI];   // [ni][mi]
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15;
-    const int fq = lane >> 4;
-    const int a_base = (wm * (MI * 16) + frow) * 8;
-    const int w_base = A_CHUNKS + (wn * (TN * 16) + frow) * 8;
-
-    const int nk = kt_end - kt_begin;
-
-    // ---- main loop ----
-    // Software pipeline over half k-tiles so that every barrier is followed by MFMA work whose operands are
-    // already in registers: after the barrier that publishes tile t+1 the wave issues the ds_reads of its first
-    // half (f0), runs the held-back second-half MFMAs of tile t (f1, read before the barrier), issues its DMA
-    // share of tile t+3 into the stage tile t just vacated, reads the second half of tile t+1 and runs its
-    // first-half MFMAs.  Ring: tile t+1 being read, t+2 landed or landing, t+3 in flight.
-    uint4 af0[MI], wf0[TN], af1[MI], wf1[TN];
-#define SDMI_READ_FRAGS(AF, WF, STAGE, KS)                                                                 \
-    do {                                                                                                   \
-        const uint4* St_ = lds + (STAGE) * STAGE_CHUNKS;                                                   \
-        const int pc_ = ((KS) * 4 + fq) ^ (frow & 7);                                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) AF[i_] = St_[a_base + i_ * 128 + pc_];           \
-        _Pragma("unroll") for (int i_ = 0; i_ < TN; ++i_) WF[i_] = St_[w_base + i_ * 128 + pc_];           \
-    } while (0)
-#define SDMI_MFMA_HALF(AF, WF)                                                                             \
-    do {                                                                                                   \
-        if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                   \
-        _Pragma("unroll") for (int ni_ = 0; ni_ < TN; ++ni_)                                               \
-            _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
-                acc[ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[ni_][mi_]);                               \
-        if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                   \
-    } while (0)
-
-    // scheduling hint for the region just written: one ds_read, then two MFMAs, MI+TN times (spreads the LDS reads
-    // of the next half under the MFMAs of this one instead of bunching them)
-#if SDMI_SCHED_INTERLEAVE
-#define SDMI_INTERLEAVE()                                                                                  \
-    do {                                                                                                   \
-        _Pragma("unroll") for (int g_ = 0; g_ < MI + TN; ++g_) {                                           \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
-        }                                                                                                  \
-    } while (0)
-#else
-#define SDMI_INTERLEAVE() do {} while (0)
-#endif
-
-    int kt_issue = 0;
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        if (kt_issue < nk) {
-            SDMI_STAGE_TILE(kt_begin + kt_issue, st);
-            ++kt_issue;
-        }
-    }
-    if (nk > 0) {
-        SDMI_WAIT_DMA(kt_issue - 1);                 // tile 0 has landed (this wave's share)
-        __syncthreads();                             // ... and everyone's
-        SDMI_READ_FRAGS(af0, wf0, 0, 0);
-        SDMI_READ_FRAGS(af1, wf1, 0, 1);
-        SDMI_MFMA_HALF(af0, wf0);
-        int rd = 1, wr = 0;                          // ring stage of tile kt+1 / of tile kt (free after the barrier)
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            SDMI_WAIT_DMA(kt_issue - kt - 2);        // tile kt+1 landed; younger tiles may still fly
-            __syncthreads();                         // every wave has finished READING tile kt as well
-            SDMI_READ_FRAGS(af0, wf0, rd, 0);
-            SDMI_MFMA_HALF(af1, wf1);                // second half of tile kt
-            SDMI_INTERLEAVE();
-            if (kt_issue < nk) {
-                SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
-                ++kt_issue;
-            }
-            SDMI_READ_FRAGS(af1, wf1, rd, 1);
-            SDMI_MFMA_HALF(af0, wf0);                // first half of tile kt+1
-            SDMI_INTERLEAVE();
-            wr = rd;
-            rd = rd == NST - 1 ? 0 : rd + 1;
-        }
-        SDMI_MFMA_HALF(af1, wf1);                    // second half of the last tile
-    }
-
-    // ---- epilogue ----
-    // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*16*MI + mi*16 + (lane&15),
-    // weight row (column of out) wcol = n0 + wn*16*TN + ni*16 + 4*(lane>>4) + j.
-    if (p.split_k > 1) {
-        // raw partial sums to the workspace slab of this slice: [split][M][tiles_n*BN] fp32
-        float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)z * p.M * ((int64_t)tiles_n * BN);
-        const int64_t ldw = (int64_t)tiles_n * BN;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int64_t wcol = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
-                *reinterpret_cast<f32x4*>(ws + m * ldw + wcol) = acc[ni][mi];
-            }
-        }
-        return;
-    }
-
-    // Common case (no GEGLU, row-major output, N % 4 == 0, column bias): all residual / embedding quads of a row
-    // block are requested before the first one is consumed, so the loads overlap instead of forming one
-    // load -> wait -> store round trip per quad.
-    if (!p.geglu && p.out_kind == 0 && (p.N & 7) == 0 && !p.bias_per_row && ((p.ld_out | p.ld_res) & 7) == 0 &&
-        (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)(2 * zoff_out) | (uintptr_t)(2 * zoff_res)) & 15) == 0) {
-        const int64_t mrow = m0 + wm * (MI * 16) + frow, ncol_w = n0 + wn * (TN * 16);
-        // pairs start on even 16-column blocks of the output: with 5 blocks per wave the odd wave column shifts by one
-        if ((TN & 1) && (wn & 1)) epilogue_rows16<DT, TN, MI, 1>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
-        else                      epilogue_rows16<DT, TN, MI, 0>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
-        return;
-    }
-    if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row && !p.res_f32) {
-        const int64_t ncol0 = n0 + wn * (TN * 16) + 4 * fq;
-        f32x4 bq[TN];
-        bool nval[TN];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int64_t n = ncol0 + ni * 16;
-            nval[ni] = n < p.N;
-            bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
-        }
-        const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
-            const bool mval = m < p.M;
-            uint2 rq[TN];
-            f32x4 eq[TN];
-            if (p.res != nullptr) {
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    rq[ni] = make_uint2(0u, 0u);
-                    if (mval && nval[ni]) rq[ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);
-                }
-            }
-            if (p.emb != nullptr) {
-                const float* e = p.emb + (mval ? m / p.rows_per_batch : 0) * p.ld_emb;
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    eq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (mval && nval[ni]) eq[ni] = *reinterpret_cast<const f32x4*>(e + ncol0 + ni * 16);
-                }
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                if (!(mval && nval[ni])) continue;
-                const int64_t n = ncol0 + ni * 16;
-                f32x4 v = acc[ni][mi] * p.alpha + bq[ni];
-                if (p.act == 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
-                } else if (p.act == 2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? gelu_erf_precise(v[j]) : gelu_erf_f(v[j]);
-                }
-                if (p.emb != nullptr) v += eq[ni];
-                if (p.res != nullptr) {
-                    float rf[4];
-                    elem_unpack4<DT>(rq[ni], rf);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += rf[j];
-                }
-                if (p.out_kind == 0) {
-                    uint2 ov;
-                    ov.x = elem_pack2<DT>(v[0], v[1]);
-                    ov.y = elem_pack2<DT>(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n) = ov;
-                } else {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n) = v;
-                }
-            }
-        }
-        return;
-    }
-
-    if (p.geglu) {
-        // GEGLU runs with TN == 4 only (host-checked): blocks (0,1) and (2,3) are (value, gate) pairs
-        f32x4 bv[TN / 2], bg[TN / 2];
-#pragma unroll
-        for (int pi = 0; pi < TN / 2; ++pi) {
-            const int64_t wcol = n0 + wn * (TN * 16) + pi * 32 + 4 * fq;
-            bv[pi] = bg[pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr && wcol + 19 < 2 * p.N) {
-                bv[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol);
-                bg[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
-            }
-        }
-        // 16-bit output with nothing else to add: the wave's two output blocks (pi = 0, 1: 32 adjacent columns) are
-        // paired through v_permlane16_swap as in epilogue_rows16 - 16-byte stores, 64 contiguous bytes per row
-        const bool wide = TN == 4 && p.out_kind == 0 && p.res == nullptr && p.emb == nullptr && !p.bias_per_row &&
-                          (p.N & 31) == 0 && (p.ld_out & 7) == 0 &&
-                          (((uintptr_t)p.out | (uintptr_t)(2 * zoff_out)) & 15) == 0;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
-            if (wide) {
-                uint2 ov[TN / 2];
-#pragma unroll
-                for (int pi = 0; pi < TN / 2; ++pi) {
-                    f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
-                    ov[pi].x = elem_pack2<DT>(v[0], v[1]);
-                    ov[pi].y = elem_pack2<DT>(v[2], v[3]);
-                }
-                const auto sx = __builtin_amdgcn_permlane16_swap(ov[0].x, ov[TN / 2 - 1].x, false, false);
-                const auto sy = __builtin_amdgcn_permlane16_swap(ov[0].y, ov[TN / 2 - 1].y, false, false);
-                // N % 32 == 0: the wave's 32 output columns are inside N or outside it as a whole
-                const int64_t n = ((n0 + wn * (TN * 16)) >> 1) + (fq & 1) * 16 + 4 * (fq & 2);
-                if (m < p.M && n < p.N)
-                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n) =
-                        make_uint4(sx[0], sy[0], sx[1], sy[1]);
-                continue;
-            }
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int pi = 0; pi < TN / 2; ++pi) {
-                const int64_t wcol = n0 + wn * (TN * 16) + pi * 32 + 4 * fq;
-                const int64_t n = (wcol >> 5) * 16 + (wcol & 15);
-                if (n >= p.N) continue;
-                f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= p.out_kind != 0 ? gelu_erf_precise(g[j]) : gelu_erf_f(g[j]);
-                store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
-            }
-        }
-        return;
-    }
-
-    // general path: partial column quads (N % 4 != 0), per-row bias, fp32 NCHW output
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int64_t n = n0 + wn * (TN * 16) + ni * 16 + 4 * fq;
-            if (n >= p.N) continue;
-            f32x4 v = acc[ni][mi] * p.alpha;
-            if (p.bias != nullptr && !p.bias_per_row) {
-                if (n + 3 < p.N) {
-                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                } else {
-                    for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
-                }
-            }
-            store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
-        }
-    }
-}
 
 // Second pass of split-K: sum the slabs and run the same epilogue.  One thread per output quad.
 template <int DT>
@@ -715,6 +60,13 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
 }
 
 }  // namespace
+
+
+#define SDMI_GEMM_UNIT_DECL(NAME)      \
+    int sdmi_gemm_unit_attrs_##NAME(); \
+    void sdmi_gemm_unit_launch_##NAME(int wide, int variant, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+SDMI_GEMM_UNIT_DECL(m0_bf16) SDMI_GEMM_UNIT_DECL(m0_f16) SDMI_GEMM_UNIT_DECL(m1_bf16) SDMI_GEMM_UNIT_DECL(m1_f16)
+#undef SDMI_GEMM_UNIT_DECL
 
 // Row tile the launcher picks: 256 rows once that still gives every CU a block, else 128 rows.
 static int pick_tile_m(int64_t M, int64_t N_w, int tile_n, int64_t problems) {
@@ -790,31 +142,22 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
             return SDMI_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    typedef void (*kern_t)(const sdmi_gemm_args);
-    // [mode][dtype][tile_n == 160][variant]: variant 0 = 128 rows / 3 stages, 1 = 256 rows / 3 stages,
-    // 2 = 128 rows / 2 stages (64-72 KiB of LDS: two blocks per CU, for short K where the epilogue of one block
-    // should overlap the main loop of another)
-#define SDMI_K(MODE, DT) {{sdmi_gemm_kernel<MODE, DT, 4, 2, 3>, sdmi_gemm_kernel<MODE, DT, 4, 4, 3>, sdmi_gemm_kernel<MODE, DT, 4, 2, 2>}, \
-                          {sdmi_gemm_kernel<MODE, DT, 5, 2, 3>, sdmi_gemm_kernel<MODE, DT, 5, 4, 3>, sdmi_gemm_kernel<MODE, DT, 5, 2, 2>}}
-    static const kern_t kernels[2][2][2][3] = {{SDMI_K(0, 0), SDMI_K(0, 1)}, {SDMI_K(1, 0), SDMI_K(1, 1)}};
-#undef SDMI_K
-    static bool attr_done = false;
-    if (!attr_done) {
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b)
-                for (int c = 0; c < 2; ++c)
-                    for (int d = 0; d < 3; ++d)
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[a][b][c][d]),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            lds_bytes(c ? 5 : 4, d == 1 ? 4 : 2, d == 2 ? 2 : 3));
-        attr_done = true;
-    }
+    // dynamic-LDS attribute of every instantiation, once per process (thread-safe; a refusal is reported, not ignored)
+    static std::once_flag attr_once;
+    static int attr_status = SDMI_OK;
+    std::call_once(attr_once, [] {
+        int (*const fns[4])() = {sdmi_gemm_unit_attrs_m0_bf16, sdmi_gemm_unit_attrs_m0_f16, sdmi_gemm_unit_attrs_m1_bf16,
+                                 sdmi_gemm_unit_attrs_m1_f16};
+        for (int i = 0; i < 4; ++i)
+            if (fns[i]() != SDMI_OK) attr_status = SDMI_ERR_LAUNCH;
+    });
+    if (attr_status != SDMI_OK) return attr_status;
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    hipLaunchKernelGGL(kernels[p.mode][f16 ? 1 : 0][wide][variant], grid, dim3(512),
-                       lds_bytes(wide ? 5 : 4, tall ? 4 : 2, variant == 2 ? 2 : 3), s, p);
+    if (p.mode == 0) (f16 ? sdmi_gemm_unit_launch_m0_f16 : sdmi_gemm_unit_launch_m0_bf16)(wide, variant, grid, s, p);
+    else             (f16 ? sdmi_gemm_unit_launch_m1_f16 : sdmi_gemm_unit_launch_m1_bf16)(wide, variant, grid, s, p);
     SDMI_CHECK_LAUNCH();
     if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);

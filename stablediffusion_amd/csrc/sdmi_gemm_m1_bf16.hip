@@ -1,0 +1,3 @@
+// sdmi_gemm instantiation unit: mode 1 (implicit-GEMM conv3x3), bf16 operands.
+#include "sdmi_gemm_kernel.h"
+SDMI_GEMM_UNIT(1, 0, m1_bf16)

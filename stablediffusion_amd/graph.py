@@ -16,7 +16,7 @@ class GraphedApplyModel:
         self.model = model
         self._key = None
         self._graph = None
-        self._x = self._t = self._out = self._cond = None
+        self._x = self._t = self._out = self._cond = self._held = None
 
     def _capture(self, x, t, cond):
         self._x, self._t, self._cond = x.clone(), t.clone(), cond
@@ -32,11 +32,18 @@ class GraphedApplyModel:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._out = self.model.apply_model(self._x, self._t, self._cond)
+        # the captured launches hold raw pointers into the packed weights and the cached cross-attention K/V of the
+        # UNet: keep both alive for as long as this graph is, whatever later eager calls do to the model's caches
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        self._held = (getattr(unet, "_pack", None), getattr(unet, "_ctx_cache", None))
+        self._gen = getattr(unet, "_generation", 0)
 
     def __call__(self, x, t, cond):
         if isinstance(cond, (dict, list, tuple)):
             return self.model.apply_model(x, t, cond)            # only the plain cross-attention form is captured
-        key = (tuple(x.shape), x.dtype, tuple(t.shape), cond.data_ptr(), tuple(cond.shape), cond._version)
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), cond.data_ptr(), tuple(cond.shape), cond._version,
+               getattr(unet, "_generation", 0))       # new weights (load_state_dict / .to()) -> re-capture
         if key != self._key:
             self._capture(x, t, cond)
             self._key = key

@@ -224,6 +224,19 @@ def _gemm_flops(a):
     return 2 * a.M * n_w * k * max(a.batch, 1)
 
 
+def _traced(kind, work, shape, launch):
+    """Run `launch()`; under TRACE bracket it with HIP events on the launch stream and log (kind, algorithmic work -
+    FLOPs for the MFMA families, bytes for the HBM-bound norms -, events, 0, shape)."""
+    if TRACE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = launch()
+    e1.record()
+    TRACE.append((kind, work, e0, e1, 0, shape))
+    return r
+
+
 def _run_gemm(a, what):
     if TRACE is None:
         hip.check(hip.lib().sdmi_gemm(C.byref(a), _stream()), what)
@@ -416,8 +429,9 @@ def groupnorm(x1, gamma, beta, eps, silu, x2=None):
     out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=x1.dtype, device=x1.device)
     nbytes = hip.lib().sdmi_groupnorm_workspace_bytes(b, hw)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x1.device)
-    hip.check(hip.lib().sdmi_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b, hw, eps,
-                                       1 if silu else 0, dt, _p(ws), nbytes, _stream()), "sdmi_groupnorm")
+    _traced("groupnorm", 2 * out.numel() * out.element_size(), (b, hw, c1 + c2),
+            lambda: hip.check(hip.lib().sdmi_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b, hw, eps,
+                                                       1 if silu else 0, dt, _p(ws), nbytes, _stream()), "sdmi_groupnorm"))
     return out
 
 
@@ -433,8 +447,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     _require(x, x.dtype, "x")
     c = x.shape[-1]
     out = torch.empty_like(x)
-    hip.check(hip.lib().sdmi_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, dt, _stream()),
-              "sdmi_layernorm")
+    _traced("layernorm", 2 * out.numel() * out.element_size(), (x.numel() // c, c),
+            lambda: hip.check(hip.lib().sdmi_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, dt,
+                                                       _stream()), "sdmi_layernorm"))
     return out
 
 
@@ -461,8 +476,10 @@ def attention_d64(q, k, v, heads, nb, nq, nk, scale, causal=False):
                                                    v.stride(0), out.stride(0), scale, _stream()), "sdmi_f32_attention_d64")
         return out
     dt = _dt(q.dtype)
-    hip.check(hip.lib().sdmi_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0), k.stride(0),
-                                           v.stride(0), out.stride(0), scale, dt, _stream()), "sdmi_attention_d64")
+    _traced("attention", 4 * nb * heads * nq * nk * 64, (nb, heads, nq, nk),
+            lambda: hip.check(hip.lib().sdmi_attention_d64(_p(q), _p(k), _p(v), _p(out), nb, heads, nq, nk, q.stride(0),
+                                                           k.stride(0), v.stride(0), out.stride(0), scale, dt, _stream()),
+                              "sdmi_attention_d64"))
     return out
 
 

@@ -40,7 +40,9 @@ class PLMSSampler(DDIMSampler):
             if cfg:
                 e_uc, e_c = out[:b].contiguous(), out[b:].contiguous()
                 return ops.lincomb([(1.0 - scale, e_uc), (scale, e_c)])
-            return out.contiguous()
+            # a fresh tensor: with hip_graph=True `out` is the graph's static output buffer, which the next replay
+            # overwrites while this eps is still needed (step 0's second evaluation, the multistep history)
+            return out.clone(memory_format=torch.contiguous_format)
 
         def x_prev_of(x, e, index):
             return ops.ddim_step(x, e.contiguous(), float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index]),

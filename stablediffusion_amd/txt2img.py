@@ -212,8 +212,8 @@ def main(args):
 
     from PIL import Image
     all_u8 = []
-    offset = 0
     for _ in range(args.n_iter):
+        offset = 0      # --cond_file holds one row per prompt of `data`; every n_iter pass walks it from the start
         for prompts in data:
             prompts = list(prompts)
             c, uc = _conditioning(model, prompts, cond_table, offset, context_dim, device)

@@ -196,8 +196,8 @@ class UNetModel(nn.Module):
         self.dtype = torch.float16 if use_fp16 else torch.float32
         self.dtype = torch.bfloat16 if use_bf16 else self.dtype
         # The reference's dtype policy (openai_model.py:602-603) selects the 16-bit MFMA operand / storage type of
-        # the HIP kernels (same MFMA rate for both).  The fp32 policy (neither flag) needs f32-MFMA kernels that are
-        # not built yet; it raises at the first forward rather than silently computing at lower precision.
+        # the HIP kernels (same MFMA rate for both); neither flag = the fp32 mode (fp32 activations, contractions
+        # through the exact 3 x bf16 split, csrc/sdmi_f32.hip).
         self.compute_dtype = self.dtype
         self.num_heads, self.num_head_channels = num_heads, num_head_channels
 
@@ -249,22 +249,26 @@ class UNetModel(nn.Module):
                                  zero_module(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
         self._pack = None
         self._ctx_cache = None
+        self._generation = 0     # bumped whenever the packed weights are dropped (graph.py keys its captures on it)
 
     # ------------------------------------------------------------------ state dict / packing
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
+    def _drop_packed(self):
         self._pack = None
+        self._ctx_cache = None   # cross-attention K/V were projected with the old to_k / to_v
+        self._generation = getattr(self, "_generation", 0) + 1
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        self._drop_packed()
         return super().load_state_dict(rename_upstream_keys(state_dict), strict=strict, **kw)
 
     def _apply(self, fn, *a, **kw):
-        self._pack = None      # .cuda() / .to(): packed weights follow the parameters
-        self._ctx_cache = None
+        self._drop_packed()      # .cuda() / .to(): packed weights follow the parameters
         return super()._apply(fn, *a, **kw)
 
     def invalidate_packed(self):
-        """Call after mutating parameters in place (packed bf16 copies are rebuilt on the next forward)."""
-        self._pack = None
-        self._ctx_cache = None
+        """Call after mutating parameters in place (packed 16-bit copies are rebuilt on the next forward)."""
+        self._drop_packed()
 
     def _res_blocks(self):
         for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):

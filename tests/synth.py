@@ -36,6 +36,28 @@ def synth_input(name, shape, scale=1.0):
     return torch.randn(tuple(shape), generator=g) * scale
 
 
+def init8d_state_dict(cls, cfg, seed=0):
+    """SURVEY.md §8(d) weight recipe: ``torch.manual_seed(seed)`` + the module's default ``nn`` initialisation, then
+    every tensor the reference zero-initialises (``zero_module``: second ResBlock conv, SpatialTransformer.proj_out,
+    the final conv - SURVEY §0.7), weight and bias, re-randomised from ONE ``Generator(1)`` stream in state-dict
+    order as ``randn * 0.02``.  ``cls(**cfg)`` must build the module tree with default init on the CPU."""
+    prev = torch.get_rng_state()
+    torch.manual_seed(seed)
+    m = cls(**cfg)
+    torch.set_rng_state(prev)
+    sd = {k: v.detach().clone().float() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    zeroed = set()
+    for name, mod in m.named_modules():
+        w = getattr(mod, "weight", None)
+        if w is not None and w.dim() >= 2 and float(w.detach().abs().max()) == 0.0:
+            zeroed.add(name)
+    for k in sd:
+        if k.rsplit(".", 1)[0] in zeroed:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+    return sd
+
+
 SD2_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
                 num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64, use_spatial_transformer=True,
                 use_linear_in_transformer=True, transformer_depth=1, context_dim=1024, legacy=False,

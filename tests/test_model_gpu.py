@@ -2,19 +2,18 @@
 reference goldens, on identical seeded weights / latents / text embeddings.
 
 Gates (BASELINE.json north_star):  relative error = max|a-b| / max|b| per tensor
-  * per-step eps/v prediction  <= 1e-2  (bf16 operands, fp32 accumulation)
+  * per-step eps/v prediction  <= 1e-2  against the reference's fp32 path  (NORTH_STAR)
   * decoded image PSNR          >= 35 dB
 
-Tolerance asserted for the bf16 path: VS_FP32 = 2.5e-2 against the plain fp32 oracle / the reference goldens
-(measured 1.0-2.1e-2 over the cases below; the worst case moves by a few 1e-3 with the split-K / tile plan,
-i.e. with the fp32 summation order),
-NOT the north-star 1e-2, and here is why.  ``oracle.model.operand_precision(bfloat16)`` re-runs the fp32
-restatement with ONLY the two operands of every contraction rounded to bf16 - what an ideal bf16 MFMA with
-fp32 accumulators computes.  On these random weights that format floor alone is 0.9-1.4e-2 from fp32
-(printed below as "format floor"; tools/precision_study.py), i.e. the north-star figure itself,
-so no bf16-operand implementation can meet 1e-2 against fp32 on every input.  The rounding noise is chaotic
-(decorrelates after a few layers), so the bf16-operand oracle is not a tighter reference either: it is
-printed for context only.  Every measured number is printed as a [parity] line.
+The benchmarked (headline) dtype is **fp16** - the operand type the reference's own v2-inference.yaml:24 selects
+(use_fp16: True) - and every fp16 case below is asserted at NORTH_STAR = 1e-2 (measured 1.3-2.7e-3).
+bf16 operands (use_bf16) run at the same MFMA rate and are kept as the secondary policy.  They are asserted at
+BF16_DOCUMENTED = 2.5e-2, NOT at the north-star figure: rounding ONLY the two operands of every contraction to bf16
+(oracle.model.operand_precision - what an ideal bf16 MFMA with fp32 accumulators computes) already costs 0.8-1.4e-2
+against fp32 on these networks, and keeping the residual stream in bf16 as well (oracle.model.storage_precision - what
+this path does) costs 1.07-1.46e-2 in the CPU emulation (tools/precision_study.py, both weight recipes).
+8 significant bits cannot meet 1e-2 on every input; 11 bits (fp16) do, with a 4-8x margin.
+Every measured number is printed as a [parity] line.
 """
 import math
 import os
@@ -28,7 +27,8 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 NORTH_STAR = 1e-2
-VS_FP32 = 2.5e-2
+BF16_DOCUMENTED = 2.5e-2      # secondary dtype only - see the module docstring; never applied to the headline dtype
+HEADLINE = "fp16"             # the dtype bench.py reports
 BF16 = torch.bfloat16
 
 
@@ -57,7 +57,8 @@ def policy(cfg, dt):
     return dict(cfg, use_fp16=(dt == "fp16"), use_bf16=(dt == "bf16"))
 
 
-TOL = {"bf16": VS_FP32, "fp16": NORTH_STAR}     # fp16 operands meet the north-star gate against plain fp32
+TOL = {"bf16": BF16_DOCUMENTED, "fp16": NORTH_STAR}
+assert TOL[HEADLINE] == NORTH_STAR
 TORCH_DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
 
@@ -111,6 +112,31 @@ def test_sd2_unet_h32_vs_reference_golden(dev, dt):
     assert (y[0, :, ::4, ::4].cpu() - sub).abs().max().item() / sub.abs().max().item() < TOL[dt]
     assert (y.flatten()[:64].cpu() - torch.from_numpy(z["unet_first64"])).abs().max().item() < TOL[dt] * scale
     assert abs(y.std().item() - float(z["unet_std"])) < 1e-2 * float(z["unet_std"])
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_sd2_unet_h32_init8d_recipe_vs_reference_golden(dev, dt):
+    """The weight recipe SURVEY.md §8(d) prescribes - default nn init under manual_seed(0), the zero_module'd tensors
+    re-randomised from Generator(1) * 0.02 (tests/synth.py:init8d_state_dict) - on the full SD2 UNet, 32x32 latent,
+    against what the reference's own layer code produced on those weights (tests/golden/sd2_init8d_h32.npz)."""
+    from stablediffusion_amd.unet import UNetModel
+    z = np.load(os.path.join(GOLD, "sd2_init8d_h32.npz"))
+    sd = synth.init8d_state_dict(UNetModel, dict(synth.SD2_UNET, use_fp16=False))
+    for k in z.files:
+        if k.startswith("fp/"):
+            np.testing.assert_array_equal(sd[k[3:]].flatten()[:4].numpy(), z[k], err_msg=f"recipe drifted: {k}")
+    with torch.device("meta"):
+        m = UNetModel(**policy(synth.SD2_UNET, dt))
+    m.load_state_dict(sd, assign=True)
+    m = m.to(dev).eval()
+    x = synth.synth_input("sd2_x", (1, 4, 32, 32)).to(dev)
+    ctx = synth.synth_input("sd2_ctx", (1, 77, 1024)).to(dev)
+    y = m(x, torch.tensor([501], device=dev), ctx)
+    sub = torch.from_numpy(z["unet_sub"])
+    e = (y[0, :, ::4, ::4].cpu() - sub).abs().max().item() / sub.abs().max().item()
+    print(f"[parity] sd2 unet h32, init8d recipe ({dt}) vs reference golden: sub-grid rel_err {e:.3e}")
+    assert e < TOL[dt]
+    assert (y.flatten()[:64].cpu() - torch.from_numpy(z["unet_first64"])).abs().max().item() < TOL[dt] * float(z["unet_absmax"])
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -232,6 +258,21 @@ def test_plms_matches_oracle(dev):
     assert rel_err(out, ref) < 5e-2
 
 
+def test_plms_hip_graph_without_cfg_matches_eager(dev):
+    """Without guidance eps_at() used to hand back the UNet output tensor itself; under hip_graph=True that is the
+    graph's static output buffer, which the second evaluation of step 0 and every later replay overwrite while the
+    multistep history still points at it.  Graph replay and eager launches must agree bit for bit."""
+    from stablediffusion_amd.plms import PLMSSampler
+    model, _ = _latent_diffusion(dev, policy(synth.TINY_UNET, "fp16"), synth.TINY_DDCONFIG)
+    x_T = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    c = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(6)).to(dev)
+    kw = dict(S=8, batch_size=2, shape=[4, 16, 16], conditioning=c, verbose=False, unconditional_guidance_scale=1.0,
+              x_T=x_T)
+    eager, _ = PLMSSampler(model).sample(**kw)
+    graphed, _ = PLMSSampler(model, hip_graph=True).sample(**kw)
+    assert torch.equal(eager, graphed)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_unet_h64_batch2_vs_oracle(dev, dt):
     """BASELINE config 1 shape: one CFG step (UNet batch 2) at a 64x64 latent, against the oracle run on
@@ -250,24 +291,45 @@ def test_unet_h64_batch2_vs_oracle(dev, dt):
     print(f"[parity] sd2 unet h64 batch 2 ({dt}): rel_err vs fp32 oracle {rel_err(y, ref):.3e} "
           f"(format floor = oracle with {dt}-rounded operands vs fp32 oracle: {rel_err(emul, ref):.3e})")
     assert rel_err(y, ref) < TOL[dt]
+    # BASELINE config 2 at its size: UNet batch 16 (8 images per GPU x CFG) at 64x64 - the benchmarked launch shapes
+    # (256-row tiles, other split-K plans than batch 2).  Samples of a batch are independent, so rows 0/1 and 14/15
+    # of a batch-16 forward that carry the batch-2 inputs must reproduce the batch-2 result that was just checked
+    # against the oracle, up to the fp32 summation order; the rows in between hold other latents / prompts / steps.
+    fill_x = synth.synth_input("h64_fill_x", (12, 4, 64, 64))
+    fill_c = synth.synth_input("h64_fill_ctx", (12, 77, 1024))
+    x16 = torch.cat([x, fill_x, x]).to(dev)
+    c16 = torch.cat([ctx, fill_c, ctx]).to(dev)
+    t16 = torch.cat([t, torch.arange(12) * 80 + 1, t]).to(dev)
+    y16 = m(x16, t16, c16)
+    assert y16.shape == (16, 4, 64, 64) and bool(torch.isfinite(y16).all())
+    for rows in ((0, 2), (14, 16)):
+        e_or = rel_err(y16[rows[0]:rows[1]], ref)
+        e_b2 = rel_err(y16[rows[0]:rows[1]], y)
+        print(f"[parity] sd2 unet h64 batch 16 ({dt}) rows {rows[0]}..{rows[1] - 1}: rel_err vs fp32 oracle {e_or:.3e}, "
+              f"vs the batch-2 forward {e_b2:.3e}")
+        assert e_or < TOL[dt] and e_b2 < TOL[dt]
 
 
 def test_unet_768_v_prediction_vs_oracle(dev):
     """BASELINE config 3 shape: SD2.1-v 768^2 = 96x96 latent, 9216-token self-attention, v-prediction head
-    (same UNet; parameterization only changes how the sampler reads the output).  One forward, batch 1, fp16
-    operands (the dtype v2-inference-v.yaml ships), against the fp32 oracle on the host cores."""
+    (same UNet; parameterization only changes how the sampler reads the output).  One forward, batch 1, in the
+    headline dtype (fp16, what v2-inference-v.yaml ships) and in bf16, against the fp32 oracle on the host cores."""
     from oracle import model as OM
     from stablediffusion_amd.unet import UNetModel
-    m, sd = build(UNetModel, policy(synth.SD2_UNET, "fp16"), "unet.", dev)
     x = synth.synth_input("h96_x", (1, 4, 96, 96))
     ctx = synth.synth_input("h96_ctx", (1, 77, 1024))
     t = torch.tensor([741])
-    y = m(x.to(dev), t.to(dev), ctx.to(dev))
-    assert y.shape == (1, 4, 96, 96) and bool(torch.isfinite(y).all())
-    with torch.no_grad():
-        ref = OM.unet_forward(sd, synth.SD2_UNET, x, t, ctx)
-    print(f"[parity] sd2 unet h96 (768^2, 9216 tokens) fp16: rel_err vs fp32 oracle {rel_err(y, ref):.3e}")
-    assert rel_err(y, ref) < NORTH_STAR
+    ref = None
+    for dt in ("fp16", "bf16"):
+        m, sd = build(UNetModel, policy(synth.SD2_UNET, dt), "unet.", dev)
+        y = m(x.to(dev), t.to(dev), ctx.to(dev))
+        assert y.shape == (1, 4, 96, 96) and bool(torch.isfinite(y).all())
+        if ref is None:
+            with torch.no_grad():
+                ref = OM.unet_forward(sd, synth.SD2_UNET, x, t, ctx)
+        print(f"[parity] sd2 unet h96 (768^2, 9216 tokens) {dt}: rel_err vs fp32 oracle {rel_err(y, ref):.3e}")
+        assert rel_err(y, ref) < TOL[dt]
+        del m, sd
 
 
 def test_non_square_latents_vs_oracle(dev):
@@ -298,23 +360,88 @@ def test_non_square_latents_vs_oracle(dev):
     assert img.shape == (1, 3, 192, 320) and e < NORTH_STAR
 
 
-@pytest.mark.parametrize("dt", ["bf16", "fp16"])
-def test_decoder_768_batch_is_per_image(dev, dt):
-    """BASELINE config 4 shape: decode_first_stage standalone at 768^2.  Size-independent property instead of a
-    CPU decode (5.6 TFLOP per image): images of a batch are independent, so decoding 4 latents at once must give
-    what decoding each alone gives (up to the fp32 summation order of the split-K plan, which depends on M)."""
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_decoder_768_batch16(dev, dt):
+    """BASELINE config 4 at its size: decode_first_stage standalone at 768^2, batch 16.  (i) Images of a batch are
+    independent, so a batch-16 decode must give what decoding a latent alone gives, up to the fp32 summation order of
+    the tile / split-K plan (which depends on M); (ii) in the headline dtype, image 0 against the fp32 oracle run on
+    the host cores (one 5.75 TFLOP CPU decode), compared on a strided sub-grid and as PSNR."""
     from stablediffusion_amd.vae import AutoencoderKL
-    vae, _ = build(AutoencoderKL, dict(ddconfig=synth.SD2_DDCONFIG, embed_dim=4), "vae.", dev)
+    vae, vsd = build(AutoencoderKL, dict(ddconfig=synth.SD2_DDCONFIG, embed_dim=4), "vae.", dev)
     vae.set_compute_dtype(TORCH_DT[dt])
-    z = synth.synth_input("z768", (4, 4, 96, 96)).to(dev)
-    full = vae.decode(z, 1 / 0.18215)
-    assert full.shape == (4, 3, 768, 768) and bool(torch.isfinite(full).all())
+    z = synth.synth_input("z768", (16, 4, 96, 96))
+    full = vae.decode(z.to(dev), 1 / 0.18215)
+    assert full.shape == (16, 3, 768, 768) and bool(torch.isfinite(full).all())
     worst = 0.0
-    for i in (0, 3):
-        one = vae.decode(z[i:i + 1].contiguous(), 1 / 0.18215)
+    for i in (0, 7, 15):
+        one = vae.decode(z[i:i + 1].contiguous().to(dev), 1 / 0.18215)
         worst = max(worst, rel_err(full[i:i + 1], one))
-    print(f"[parity] sd2 decoder 768^2 batch 4 vs per-image ({dt}): rel_err {worst:.3e}")
+    print(f"[parity] sd2 decoder 768^2 batch 16 vs per-image ({dt}): rel_err {worst:.3e}")
     assert worst < TOL[dt]      # rounding noise of the operand format, re-ordered by a different tile plan
+    if dt == HEADLINE:
+        from oracle import model as OM
+        with torch.no_grad():
+            ref = OM.vae_decode(vsd, synth.SD2_DDCONFIG, z[:1] / 0.18215)
+        got = full[:1].cpu()
+        e_sub = rel_err(got[:, :, ::8, ::8], ref[:, :, ::8, ::8])
+        e_all = rel_err(got, ref)
+        db = psnr(got, ref, float(ref.max() - ref.min()))
+        print(f"[parity] sd2 decoder 768^2 batch 16, image 0 ({dt}) vs fp32 oracle: sub-grid rel_err {e_sub:.3e}, "
+              f"full rel_err {e_all:.3e}, PSNR {db:.1f} dB")
+        assert e_sub < NORTH_STAR and e_all < NORTH_STAR and db >= 35.0
+
+
+def test_upstream_spelled_checkpoint_through_txt2img_loader(dev, tmp_path):
+    """SURVEY.md §8(f) rank 2 on the GPU: a Lightning-style checkpoint ({"state_dict", "global_step"}, txt2img.py:32-37)
+    whose keys use the UPSTREAM spellings (time_embed, emb_layers, op, proj_in, ff, upsample - SURVEY §0.5) goes
+    through txt2img.load_model_from_config (txt2img.py:21-64; non-executing reader, strict=False) with
+    vae_attn="standard" (what real SD weights need); UNet step and decode then match the oracle on those weights."""
+    from oracle import model as OM
+    from oracle import sampler as OSamp
+    from stablediffusion_amd import txt2img
+    cfg = {"model": {"target": "ldm.models.diffusion.ddpm.LatentDiffusion", "params": {
+        "linear_start": 0.00085, "linear_end": 0.012, "timesteps": 1000, "scale_factor": 0.18215,
+        "conditioning_key": "crossattn", "parameterization": "eps",
+        "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.TINY_UNET)},
+        "first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL",
+                               "params": {"embed_dim": 4, "ddconfig": dict(synth.TINY_DDCONFIG), "vae_attn": "standard"}},
+        "cond_stage_config": "__is_unconditional__", "force_null_conditioning": True}}}
+    with torch.device("meta"):
+        shapes = {k: v.shape for k, v in txt2img.instantiate_from_config(cfg["model"]).state_dict().items()}
+    ups = [("time_embedding.", "time_embed."), (".embedding_layers.", ".emb_layers."), (".operation.", ".op."),
+           (".project_in.", ".proj_in."), (".feed_forward.net.", ".ff.net."), (".up_sample.", ".upsample.")]
+
+    def upstream(k):
+        for a, b in ups:
+            k = k.replace(a, b)
+        return k
+    sd_up = {upstream(k): synth.synth_tensor(k, s) for k, s in shapes.items()}
+    assert any(".emb_layers." in k for k in sd_up) and any(".proj_in." in k for k in sd_up) and \
+        any(".op." in k for k in sd_up) and any(".ff.net." in k for k in sd_up) and any(".upsample." in k for k in sd_up) \
+        and not any(".embedding_layers." in k or ".project_in." in k or ".up_sample." in k for k in sd_up)
+    ckpt = tmp_path / "upstream.ckpt"
+    torch.save({"state_dict": sd_up, "global_step": 7}, ckpt)
+    model = txt2img.load_model_from_config(cfg, str(ckpt), device=dev)
+    assert model.first_stage_model.decoder.vae_attn == "standard"
+    # nothing was left at its constructor value: every parameter equals the checkpoint's tensor
+    got = model.state_dict()
+    for k, s_ in shapes.items():
+        assert torch.equal(got[k].cpu(), sd_up[upstream(k)]), k
+    unet_sd = {k[len("model.diffusion_model."):]: v for k, v in sd_up.items() if k.startswith("model.diffusion_model.")}
+    vae_sd = {k[len("first_stage_model."):]: v for k, v in sd_up.items() if k.startswith("first_stage_model.")}
+    x = synth.synth_input("ck_x", (2, 4, 16, 16))
+    ctx = synth.synth_input("ck_ctx", (2, 7, 96))
+    t = torch.tensor([801, 41])
+    y = model.apply_model(x.to(dev), t.to(dev), ctx.to(dev))
+    img = model.decode_first_stage(x.to(dev))
+    with torch.no_grad():
+        ref = OSamp.apply_model(unet_sd, synth.TINY_UNET, x, t, ctx)          # the oracle reads upstream spellings too
+        iref = OSamp.decode_first_stage(vae_sd, synth.TINY_DDCONFIG, x, 0.18215, vae_attn="standard")
+        iref_literal = OSamp.decode_first_stage(vae_sd, synth.TINY_DDCONFIG, x, 0.18215, vae_attn="reference")
+    print(f"[parity] upstream-spelled checkpoint (fp16, vae_attn=standard): unet rel_err {rel_err(y, ref):.3e}, "
+          f"decode rel_err {rel_err(img, iref):.3e} (vs the literal-reference contraction {rel_err(img, iref_literal):.3e})")
+    assert rel_err(y, ref) < NORTH_STAR and rel_err(img, iref) < NORTH_STAR
+    assert rel_err(img, iref_literal) > 5 * rel_err(img, iref)       # the switch really selects the other contraction
 
 
 def test_txt2img_main_end_to_end(dev, tmp_path):

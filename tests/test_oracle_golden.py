@@ -164,6 +164,25 @@ def test_sd2_full_size_h32():
     close(img[0, :, ::16, ::16], T(z, "dec_sub"), 1e-4)
 
 
+@pytest.mark.slow
+def test_sd2_init8d_recipe_h32():
+    """SURVEY.md §8(d) weight recipe (default nn init under manual_seed(0), zero_module'd tensors Generator(1) * 0.02):
+    the oracle against what the reference's own layer code produced on the same weights (gen_full_init8d)."""
+    z = load("sd2_init8d_h32")
+    from stablediffusion_amd.unet import UNetModel
+    sd = synth.init8d_state_dict(UNetModel, dict(synth.SD2_UNET, use_fp16=False))
+    for k in z.files:
+        if k.startswith("fp/"):        # the recipe reproduces the very weights the golden was made with
+            np.testing.assert_array_equal(sd[k[3:]].flatten()[:4].numpy(), z[k], err_msg=k)
+    x = synth.synth_input("sd2_x", (1, 4, 32, 32))
+    ctx = synth.synth_input("sd2_ctx", (1, 77, 1024))
+    with torch.no_grad():
+        y = OM.unet_forward(sd, synth.SD2_UNET, x, torch.tensor([501]), ctx)
+    close(y.flatten()[:64], T(z, "unet_first64"), 1e-4)
+    close(y[0, :, ::4, ::4], T(z, "unet_sub"), 1e-4)
+    assert abs(y.std().item() - float(z["unet_std"])) < 1e-4 * float(z["unet_std"])
+
+
 def test_vae_encoder_and_gaussian_vs_reference_golden():
     """The oracle's Encoder / DiagonalGaussianDistribution restatement against what the reference's own
     model.py:145-279 / distribution.py:10-43 produced (tools/gen_golden.py gen_tiny_encoder)."""

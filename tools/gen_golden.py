@@ -306,16 +306,41 @@ def gen_full(ref):
          dec_params=np.asarray(sum(p.numel() for p in d.parameters())))
 
 
+@torch.no_grad()
+def gen_full_init8d(ref):
+    """SD2-size UNet at h=32 on the SURVEY.md §8(d) weight recipe (default nn init under manual_seed(0); zero_module'd
+    tensors Generator(1) * 0.02 - tests/synth.py:init8d_state_dict), run through the reference's own layer code."""
+    from stablediffusion_amd.unet import UNetModel
+    cfg = dict(synth.SD2_UNET, use_fp16=False)
+    sd = synth.init8d_state_dict(UNetModel, cfg)
+    u = build_ref_unet(ref, cfg)
+    missing = u.load_state_dict(sd, strict=True)
+    x = synth.synth_input("sd2_x", (1, 4, 32, 32))
+    t = torch.tensor([501], dtype=torch.long)
+    ctx = synth.synth_input("sd2_ctx", (1, 77, 1024))
+    y = u(x, t, ctx)
+    # fingerprints of the weights, so that a test can tell "the recipe produced other weights here" from a parity failure
+    fp = {k: sd[k].flatten()[:4].clone() for k in ("input_blocks.0.0.weight", "out.2.weight", "middle_block.1.proj_out.weight",
+                                                   "output_blocks.11.0.out_layers.3.weight", "time_embedding.2.bias")}
+    save("sd2_init8d_h32", unet_sub=y[0, :, ::4, ::4], unet_first64=y.flatten()[:64], unet_std=y.std(), unet_absmax=y.abs().max(),
+         **{"fp/" + k: v for k, v in fp.items()})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only-init8d", action="store_true", help="write tests/golden/sd2_init8d_h32.npz only")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     reference = load_reference()
+    if args.only_init8d:
+        gen_full_init8d(reference)
+        raise SystemExit(0)
     gen_leaves(reference)
     gen_tables(reference)
     gen_tiny_composites(reference)
     gen_tiny_encoder(reference)
     if args.full:
         gen_full(reference)
+        gen_full_init8d(reference)

@@ -1,56 +1,60 @@
 #!/usr/bin/env python3
-"""CPU study: which bf16 roundings of the HIP pipeline cost how much end-to-end error.
-Monkeypatches the oracle's conv/linear/norm helpers with bf16 rounding at chosen places and reports
-max|a-b|/max|b| against the plain fp32 oracle.  (Development aid, not part of the product or tests.)"""
-import sys, os
+"""CPU study (development aid; uses the oracle, never the product path): what the 16-bit formats cost end to end.
+
+For each weight recipe and UNet configuration, max|a-b|/max|b| (and rms-relative) of the oracle run with
+  operands   : only the two operands of every contraction rounded (oracle.model.operand_precision) - the floor of an
+               MFMA path with that operand type, whatever else it stores in fp32
+  + storage  : additionally the residual stream / norm inputs rounded (oracle.model.storage_precision) - what the
+               HIP path does when it keeps the stream in a 16-bit type
+against the plain fp32 oracle.
+
+Weight recipes:
+  synth  : tests/synth.py - every tensor randn * fan_in^-0.5 (biases 0.05, norm scales 1 +- 0.1)
+  init8d : SURVEY.md §8(d) - torch.manual_seed(0), default nn init, the zero_module'd tensors re-randomised with
+           Generator(1), randn * 0.02
+usage: precision_study.py [tiny|sd2] [synth|init8d]
+"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, torch.nn.functional as F
+import torch
+
 from oracle import model as OM
 from tests import synth
 
-q = lambda x: x.bfloat16().float()
 
-def run(cfgname, rw, rin, rout, rnorm, rstream, rx=True, remb=True):
-    cfg = synth.TINY_UNET if cfgname == "tiny" else synth.SD2_UNET
+def weights(cfg, recipe):
     from stablediffusion_amd.unet import UNetModel
-    with torch.device("meta"):
-        shapes = {k: v.shape for k, v in UNetModel(**cfg).state_dict().items()}
-    sd = {k: synth.synth_tensor("unet." + k, s) for k, s in shapes.items()}
-    if cfgname == "tiny":
-        x = synth.synth_input("tiny_x", (2, 4, 16, 16)); t = torch.tensor([981, 21]); ctx = synth.synth_input("tiny_ctx", (2, 7, 96))
-    else:
-        x = synth.synth_input("sd2_x", (1, 4, 32, 32)); t = torch.tensor([501]); ctx = synth.synth_input("sd2_ctx", (1, 77, 1024))
-    with torch.no_grad():
-        ref = OM.unet_forward(sd, cfg, x, t, ctx)
-        o_conv, o_lin, o_gn, o_ln = OM._conv, OM._lin, OM._gn, F.layer_norm
-        o_gnF = F.group_norm
-        def conv(sd_, p, xx, stride=1):
-            w = sd_[p + "weight"]; w = q(w) if rw else w
-            xi = q(xx) if rin else xx
-            y = F.conv2d(xi, w, sd_.get(p + "bias"), stride=stride, padding=w.shape[-1] // 2)
-            return q(y) if rout else y
-        def lin(sd_, p, xx):
-            w = sd_[p + "weight"]; w = q(w) if rw else w
-            xi = q(xx) if rin else xx
-            y = F.linear(xi, w, sd_.get(p + "bias"))
-            return q(y) if rout else y
-        def gn(sd_, p, xx, eps):
-            y = o_gn(sd_, p, xx, eps)
-            return q(y) if rnorm else y
-        OM._conv, OM._lin, OM._gn = conv, lin, gn
-        try:
-            y = OM.unet_forward(sd, cfg, q(x) if rx else x, t, q(ctx) if rin else ctx)
-        finally:
-            OM._conv, OM._lin, OM._gn = o_conv, o_lin, o_gn
-    return ((y - ref).abs().max() / ref.abs().max()).item(), ((y - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    if recipe == "synth":
+        with torch.device("meta"):
+            shapes = {k: v.shape for k, v in UNetModel(**cfg).state_dict().items()}
+        return {k: synth.synth_tensor("unet." + k, s) for k, s in shapes.items()}
+    return synth.init8d_state_dict(UNetModel, cfg)
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
 
 if __name__ == "__main__":
     name = sys.argv[1] if len(sys.argv) > 1 else "tiny"
-    for label, kw in [
-        ("weights only", dict(rw=1, rin=0, rout=0, rnorm=0, rstream=0, rx=False)),
-        ("x input only", dict(rw=0, rin=0, rout=0, rnorm=0, rstream=0, rx=True)),
-        ("operands (acts in) only", dict(rw=0, rin=1, rout=0, rnorm=0, rstream=0, rx=False)),
-        ("weights + operands", dict(rw=1, rin=1, rout=0, rnorm=0, rstream=0, rx=True)),
-        ("weights + operands + all outputs", dict(rw=1, rin=1, rout=1, rnorm=1, rstream=1, rx=True)),
-    ]:
-        print(f"{name:5s} {label:40s} max-rel {run(name, **kw)[0]:.3e}  rms-rel {run(name, **kw)[1]:.3e}")
+    recipe = sys.argv[2] if len(sys.argv) > 2 else "synth"
+    torch.set_num_threads(8)
+    cfg = synth.TINY_UNET if name == "tiny" else synth.SD2_UNET
+    sd = weights(cfg, recipe)
+    if name == "tiny":
+        x = synth.synth_input("tiny_x", (2, 4, 16, 16)); t = torch.tensor([981, 21]); ctx = synth.synth_input("tiny_ctx", (2, 7, 96))
+    else:
+        x = synth.synth_input("sd2_x", (1, 4, 32, 32)); t = torch.tensor([501]); ctx = synth.synth_input("sd2_ctx", (1, 77, 1024))
+    B, H = torch.bfloat16, torch.float16
+    with torch.no_grad():
+        ref = OM.unet_forward(sd, cfg, x, t, ctx)
+        print(f"{name} / {recipe}: |ref| max {ref.abs().max():.4f} std {ref.std():.4f}")
+        for label, op, st in (("bf16 operands", B, None), ("bf16 operands + bf16 storage", B, B),
+                              ("bf16 operands + fp16 storage", B, H), ("fp16 operands", H, None),
+                              ("fp16 operands + fp16 storage", H, H)):
+            with OM.operand_precision(op), OM.storage_precision(st):
+                y = OM.unet_forward(sd, cfg, x.to(op).float() if st is not None else x, t, ctx)
+            m, r = rel(y, ref)
+            print(f"  {label:34s} max-rel {m:.3e}  rms-rel {r:.3e}")
