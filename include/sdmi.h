@@ -31,7 +31,8 @@ typedef enum sdmi_status {
     SDMI_ERR_BAD_ARG = -1,      /* null pointer / non-positive size / unsupported combination */
     SDMI_ERR_ALIGNMENT = -2,    /* a leading dimension or channel count breaks the 16-byte vector rule */
     SDMI_ERR_WORKSPACE = -3,    /* workspace missing or too small */
-    SDMI_ERR_LAUNCH = -4        /* hipLaunchKernel reported an error */
+    SDMI_ERR_LAUNCH = -4,       /* hipLaunchKernel (or another HIP runtime call) reported an error */
+    SDMI_ERR_TOO_LARGE = -5     /* the problem exceeds the fixed scratch of a no-allocation entry point */
 } sdmi_status;
 
 /* 16-bit storage / MFMA operand type of activations and packed weights.  Mirrors the reference's dtype
@@ -39,7 +40,8 @@ typedef enum sdmi_status {
 typedef enum sdmi_dtype { SDMI_DTYPE_BF16 = 0, SDMI_DTYPE_F16 = 1 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 3: + sdmi_f32_embed_tokens, sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2 (2: dtype, fp32 mode) */
+int sdmi_abi_version(void);   /* 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+                                 sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
  * GEMM / implicit-GEMM convolution on 16-bit (bf16 | f16) MFMA, fp32 accumulate:
@@ -120,6 +122,23 @@ int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2,
                    int32_t nb, int64_t hw, float eps, int32_t silu, int32_t dtype,
                    void* workspace, int64_t workspace_bytes, void* stream);
 int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw);
+
+/* sdmi_groupnorm without a workspace argument, for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference (which allocates freely
+ * through PyTorch): same arguments, kernels and results as sdmi_groupnorm, but the per-slab statistics live in a
+ * static device array inside the library (SDMI_GROUPNORM_NOALLOC_MAX_BYTES per GPU, held until the process ends)
+ * instead of caller memory; no hipMalloc / hipFree / allocating routine is called.
+ *   - limit: sdmi_groupnorm_workspace_bytes(nb, hw) <= SDMI_GROUPNORM_NOALLOC_MAX_BYTES, i.e. nb * slabs(hw) <= 4096
+ *     (slabs(hw) = 1 up to 1024 pixels, else ceil(hw / max(64, ceil(hw / 256))) <= 256: e.g. 16 images of any size);
+ *     beyond it the call returns SDMI_ERR_TOO_LARGE and launches nothing.
+ *   - the array's device address is looked up on the first call made with a device current (hipGetSymbolAddress, once
+ *     per device, per-device pointer kept): make one call outside any stream capture first.
+ *   - every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams) race - serialise them.
+ *     Nothing has to be cleared between calls: each call overwrites every entry it later reads. */
+#define SDMI_GROUPNORM_NOALLOC_MAX_BYTES (4096 * 32 * 3 * 4)
+int sdmi_groupnorm_noalloc(const void* x1, const void* x2, int32_t C1, int32_t C2,
+                           const float* gamma, const float* beta, void* out,
+                           int32_t nb, int64_t hw, float eps, int32_t silu, int32_t dtype, void* stream);
 
 /* LayerNorm over the last dim C of a 16-bit [rows, C] matrix, fp32 statistics, affine.
  * Replaces nn.LayerNorm at attention.py:512-514 (called :525-527).  C % 8 == 0. */

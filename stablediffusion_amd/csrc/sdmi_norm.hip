@@ -10,6 +10,7 @@
 //                                   y = silu(x * scale[c] + shift[c]) with scale/shift tables in LDS
 // The second read of x in pass 2 is served from L2 / Infinity Cache for the UNet's tensor sizes.
 // The input may be the channel concatenation of two tensors (two base pointers).
+#include <mutex>
 #include "sdmi_common.h"
 
 namespace {
@@ -330,9 +331,9 @@ extern "C" int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw) {
     return (int64_t)nb * nslab * GN_GROUPS * 3 * (int64_t)sizeof(float);
 }
 
-extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma,
-                              const float* beta, void* out, int32_t nb, int64_t hw, float eps, int32_t silu,
-                              int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+// Argument checks shared by the two GroupNorm entry points (everything except the scratch buffer).
+static int groupnorm_check(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma, const float* beta,
+                           const void* out, int32_t nb, int64_t hw, int32_t dtype) {
     if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
     if (x1 == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (nb <= 0 || hw <= 0 || C1 <= 0 || C2 < 0) return SDMI_ERR_BAD_ARG;
@@ -340,7 +341,15 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     const int C = C1 + C2;
     if (C1 % 8 != 0 || C2 % 8 != 0 || C % GN_GROUPS != 0) return SDMI_ERR_ALIGNMENT;
     if (2 * C * (int)sizeof(float) > 64 * 1024) return SDMI_ERR_BAD_ARG;
-    if (workspace == nullptr || workspace_bytes < sdmi_groupnorm_workspace_bytes(nb, hw)) return SDMI_ERR_WORKSPACE;
+    return SDMI_OK;
+}
+
+// The launches of both entry points; `partial` = nb * nslab * 32 * 3 floats of scratch (per-slab group summaries:
+// every entry is written by gn_stats_kernel before gn_apply_kernel reads it, so the buffer needs no clearing).
+static int groupnorm_launch(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma, const float* beta,
+                            void* out, int32_t nb, int64_t hw, float eps, int32_t silu, int32_t dtype, float* partial,
+                            void* stream) {
+    const int C = C1 + C2;
     // Small images (<= 1024 pixels): one slab per image and one fused launch; else P-pixel slabs and two launches.
     const bool fused = hw <= 1024;
     const int64_t P = fused ? hw : gn_slab_pixels(hw);
@@ -349,7 +358,6 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
     int gch = 1;
     while (gch < GN_GROUPS && (int64_t)nslab * nb * gch < 512 && (C / (gch * 2)) % 8 == 0) gch *= 2;
     const int Cw = C / gch;
-    float* partial = reinterpret_cast<float*>(workspace);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)nslab, (unsigned)nb, (unsigned)gch);
     const size_t lds = 2 * (size_t)Cw * sizeof(float);
@@ -377,6 +385,51 @@ extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_
         hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
+}
+
+extern "C" int sdmi_groupnorm(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma,
+                              const float* beta, void* out, int32_t nb, int64_t hw, float eps, int32_t silu,
+                              int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+    const int st = groupnorm_check(x1, x2, C1, C2, gamma, beta, out, nb, hw, dtype);
+    if (st != SDMI_OK) return st;
+    if (workspace == nullptr || workspace_bytes < sdmi_groupnorm_workspace_bytes(nb, hw)) return SDMI_ERR_WORKSPACE;
+    return groupnorm_launch(x1, x2, C1, C2, gamma, beta, out, nb, hw, eps, silu, dtype, reinterpret_cast<float*>(workspace),
+                            stream);
+}
+
+// ---- sdmi_groupnorm_noalloc: the same GroupNorm for callers that cannot allocate ---------------------------------
+// The slab partials live in a file-scope device array instead of a caller workspace.  Each GPU holds its own copy
+// of the array at its own address: the address is looked up once per device with hipGetSymbolAddress (on the first
+// call made with that device current) and only that pointer - never the array's name - is handed to the kernels.
+constexpr int64_t GN_NOALLOC_MAX_SLABS = 4096;                                  // nb * slabs-per-image
+constexpr int64_t GN_NOALLOC_FLOATS = GN_NOALLOC_MAX_SLABS * GN_GROUPS * 3;     // 1.5 MiB per GPU
+static __device__ __align__(256) float scratch[GN_NOALLOC_FLOATS];
+
+constexpr int GN_MAX_DEVICES = 64;
+static std::mutex scratch_mutex;
+static float* scratch_ptr[GN_MAX_DEVICES] = {};
+
+static_assert(GN_NOALLOC_FLOATS * (int64_t)sizeof(float) == SDMI_GROUPNORM_NOALLOC_MAX_BYTES, "limit stated in sdmi.h");
+
+extern "C" int sdmi_groupnorm_noalloc(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma,
+                                      const float* beta, void* out, int32_t nb, int64_t hw, float eps, int32_t silu,
+                                      int32_t dtype, void* stream) {
+    const int st = groupnorm_check(x1, x2, C1, C2, gamma, beta, out, nb, hw, dtype);
+    if (st != SDMI_OK) return st;
+    if (sdmi_groupnorm_workspace_bytes(nb, hw) > SDMI_GROUPNORM_NOALLOC_MAX_BYTES) return SDMI_ERR_TOO_LARGE;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEVICES) return SDMI_ERR_LAUNCH;
+    float* ptr;
+    {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        if (scratch_ptr[dev] == nullptr) {
+            void* sym = nullptr;
+            if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || sym == nullptr) return SDMI_ERR_LAUNCH;
+            scratch_ptr[dev] = reinterpret_cast<float*>(sym);
+        }
+        ptr = scratch_ptr[dev];
+    }
+    return groupnorm_launch(x1, x2, C1, C2, gamma, beta, out, nb, hw, eps, silu, dtype, ptr, stream);
 }
 
 extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows,
