@@ -37,10 +37,13 @@ typedef enum sdmi_status {
 
 /* 16-bit storage / MFMA operand type of activations and packed weights.  Mirrors the reference's dtype
  * policy (openai_model.py:602-603: use_fp16 -> float16, use_bf16 -> bfloat16); both run at the same MFMA rate. */
-typedef enum sdmi_dtype { SDMI_DTYPE_BF16 = 0, SDMI_DTYPE_F16 = 1 } sdmi_dtype;
+typedef enum sdmi_dtype {
+    SDMI_DTYPE_BF16 = 0, SDMI_DTYPE_F16 = 1,
+    SDMI_DTYPE_F32_PLANES = 2    /* sdmi_pack_* only: the six bf16 piece planes of the fp32 mode (see sdmi_f32_split3) */
+} sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -53,9 +56,9 @@ int sdmi_abi_version(void);   /* 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE
  * openai_model.py:106-114 / model.py:137-141 (fused gather); torch.cat([h, skip]) feeding a 1x1
  * conv at openai_model.py:1010 (two-pointer A).
  *
- * W is PRE-PACKED by the caller: 16-bit [Npad][K], K contiguous, Npad = N_w rounded up to tile_n
+ * W is PRE-PACKED (sdmi_pack_* below): 16-bit [Npad][K], K contiguous, Npad = N_w rounded up to tile_n
  * (128, or 160 for widths that are multiples of 160 -- no GEGLU), rows >= N_w zero.  K must be a
- * multiple of 64 (pad with zero columns).
+ * multiple of 64 (zero columns).
  *   mode 0 (linear / 1x1 conv): A is [M, lda] row-major; if A2 != NULL columns [0,k_split) come
  *       from A and [k_split,K) from A2 (row stride lda2); k_split % 64 == 0.  If the logical width of A
  *       is not a multiple of 64, pass it as k_valid: columns [k_valid, K) read as zero.
@@ -106,6 +109,42 @@ int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing: fp32 weights in the reference's own (PyTorch state-dict) layout -> the pre-packed W operand that
+ * sdmi_gemm reads.  Replaces nothing at run time: it is the one-time preparation of nn.Linear.weight [N, K]
+ * (attention.py:81,117,213,224,291-296; openai_model.py:218,618-620), of GEGLU.proj.weight [2*inner, K]
+ * (attention.py:81-91) and of nn.Conv2d.weight [Cout, Cin, 3, 3] (openai_model.py:85,139,195,234,663,927;
+ * model.py:122,329,369,433,440) that the reference leaves to cuDNN / cuBLAS heuristics.
+ * Packed buffer: 16-bit [Npad][Kp], Npad = rows_total rounded up to tile_n (128 | 160; sdmi_pack_tile_n gives the
+ * tile the Python host uses: 160 where it divides N and the layer is not GEGLU), Kp = sdmi_pack_linear_k /
+ * sdmi_pack_conv3x3_k, padding zero; sdmi_pack_bytes(rows_total, Kp, tile_n) bytes, allocated by the caller.
+ *   linear : row n, column k as they stand.  Several weights that share an input (q|k|v, the 22 embedding
+ *            projections) are concatenated along N by one call each: rows [row_offset, row_offset + N) of a buffer
+ *            of rows_total rows; the call that holds the last row also writes the zero rows up to Npad.
+ *   geglu  : rows interleaved [16 value | 16 gate] per 32 (see sdmi_gemm above); bias (may be NULL) permuted alike.
+ *   conv3x3: column (ky*3 + kx) * Cin_p + ci with Cin_p = sdmi_pack_conv3x3_cin (pass it as sdmi_gemm_args.Cin; the
+ *            activation must carry that many channels, zeros beyond Cin).
+ * dtype: SDMI_DTYPE_BF16 | SDMI_DTYPE_F16 (the MFMA operand type), or SDMI_DTYPE_F32_PLANES - the fp32 mode: six bf16
+ * planes (w0 w1 w0 w2 w1 w0), w = w0 + w1 + w2 exactly, of width K (Cin) rounded up to 32, inside every conv tap.
+ * Device entry points take device pointers and run asynchronously on `stream`; the *_host twins take host pointers
+ * and run the same arithmetic on the CPU (weights prepared off the GPU; the CPU test suite) - bit-identical results.
+ * ---------------------------------------------------------------------------------------- */
+int32_t sdmi_pack_tile_n(int64_t N, int32_t geglu);
+int64_t sdmi_pack_linear_k(int64_t K, int32_t dtype);
+int64_t sdmi_pack_conv3x3_cin(int64_t Cin, int32_t dtype);
+int64_t sdmi_pack_conv3x3_k(int64_t Cin, int32_t dtype);
+int64_t sdmi_pack_bytes(int64_t rows_total, int64_t k_packed, int32_t tile_n);
+int sdmi_pack_linear(const float* w, int64_t N, int64_t K, int64_t ld_w, int64_t row_offset, int64_t rows_total,
+                     void* out, int32_t dtype, int32_t tile_n, void* stream);
+int sdmi_pack_geglu(const float* w, const float* bias, int64_t inner, int64_t K, int64_t ld_w, void* out,
+                    float* bias_out, int32_t dtype, void* stream);
+int sdmi_pack_conv3x3(const float* w, int64_t Cout, int64_t Cin, void* out, int32_t dtype, int32_t tile_n, void* stream);
+int sdmi_pack_linear_host(const float* w, int64_t N, int64_t K, int64_t ld_w, int64_t row_offset, int64_t rows_total,
+                          void* out, int32_t dtype, int32_t tile_n);
+int sdmi_pack_geglu_host(const float* w, const float* bias, int64_t inner, int64_t K, int64_t ld_w, void* out,
+                         float* bias_out, int32_t dtype);
+int sdmi_pack_conv3x3_host(const float* w, int64_t Cout, int64_t Cin, void* out, int32_t dtype, int32_t tile_n);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) [+ SiLU] over an NHWC 16-bit tensor, fp32 statistics.

@@ -15,10 +15,23 @@
 // younger tile stays in flight across the barrier.  Swizzles (applied to the SOURCE address, the DMA writes
 // linearly): K chunk ^= (row>>1)&7 (conflict-free b128 reads for 32 rows at one chunk), V chunk ^= ((row>>1)&1)<<2
 // (conflict-free transposed reads).  Keys past Nk are fetched from a zero constant.
+// Softmax: one fma per logit puts it in log2 units relative to the running maximum (s * c - m), one v_exp_f32 makes
+// the probability.  The running maximum is only moved when a tile exceeds it by more than 2^8 (probabilities stay
+// <= 256: exact in fp32, in range for f16), which makes the rescale of O and l a rare, wave-uniform branch.
+// Measured and dropped (MI355X, N = 4096): folding scale * log2(e) into the query projection and starting the QK^T
+// accumulator at -m instead of 0, so that a probability is a bare exp2 - 32 fewer VALU per tile, yet 8 % SLOWER
+// (846 against 920 TFLOP/s): an MFMA whose C operand is a VGPR block other than its destination costs more than
+// the fmas it saves.  What did pay (+24 %): keeping hipcc's wait for the Q fragment loads out of the loop (below).
 #include "sdmi_common.h"
 
 #ifndef SDMI_ATTN_OCC
 #define SDMI_ATTN_OCC 2
+#endif
+#ifndef SDMI_ATTN_NST
+#define SDMI_ATTN_NST 3
+#endif
+#ifndef SDMI_ATTN_HOIST
+#define SDMI_ATTN_HOIST 0      // 1: pin every LDS fragment read of a tile ahead of its MFMA group (A/B: +-1 %, 22 more VGPRs)
 #endif
 
 namespace {
@@ -27,7 +40,7 @@ constexpr int QB = 128;      // query rows per workgroup
 constexpr int KB = 64;       // keys per tile
 constexpr int D = 64;
 constexpr int TILE_CH = KB * (D / 8);   // 16-byte chunks per K or V tile (512)
-constexpr int NST = 3;                  // ring stages
+constexpr int NST = SDMI_ATTN_NST;      // ring stages (3: tile t+2 in flight across the barrier; 2: tile t+1 only)
 
 __device__ const uint4 attn_zero16 = {0u, 0u, 0u, 0u};
 
@@ -45,6 +58,9 @@ __device__ __forceinline__ uint4 cvt8(const f32x16& s, int base) {
     for (int j = 0; j < 8; ++j) f[j] = s[base + j];
     return elem_pack8<DT>(f);
 }
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr float RESCALE_THR = 8.0f;     // log2 units: move the running maximum only when a tile tops it by 2^8
 
 template <int DT>
 __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const AttnArgs p) {
@@ -72,18 +88,13 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     const unsigned short* Vp = p.v + (int64_t)b * p.Nk * p.ldv + h * D;
     unsigned short* Op = p.out + (int64_t)b * p.Nq * p.ldo + h * D;
 
-    // Q fragments (B operand of S^T = K Q^T): lane (q = lr, half hf), k-step s: Q[q][16s + 8hf .. +7]
     const int qrow = qblk * QB + wid * 32 + lr;
     const int qrow_c = qrow < p.Nq ? qrow : p.Nq - 1;
-    uint4 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = *reinterpret_cast<const uint4*>(Qp + (int64_t)qrow_c * p.ldq + 16 * s + 8 * hf);
 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -1e30f, l_run = 0.f;
+    float nm = 0.f, l_run = 0.f;       // nm = -(running maximum), log2 units
 
     // ---- staging: wave w issues, per tile, K rows {8w..8w+7, 32+8w..} and the same V rows: 4 DMA instructions ----
     // lane l of an instruction owns physical chunk l&7 of row R = 32*i + 8*w + (l>>3) and fetches the logical chunk
@@ -118,12 +129,18 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
 
     const int ntiles = (p.Nk + KB - 1) / KB;
     ATTN_STAGE_TILE(0, 0);
-    if (ntiles > 1) {
-        ATTN_STAGE_TILE(1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tile 0 landed (this wave's share); tile 1 may fly
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (NST == 3 && ntiles > 1) ATTN_STAGE_TILE(1, 1);
+    // Q fragments (B operand of S^T = K Q^T): lane (q = lr, half hf), k-step s: Q[q][16s + 8hf .. +7].
+    // They are consumed (empty asm) right here so that hipcc retires its own wait for them BEFORE the loop: left to
+    // itself it puts `s_waitcnt vmcnt(3..0)` ahead of the first uses inside the loop, where the counter also holds the
+    // LDS-DMA of the tile just issued - every iteration would then wait for its own prefetch.
+    u32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = *reinterpret_cast<const u32x4*>(Qp + (int64_t)qrow_c * p.ldq + 16 * s + 8 * hf);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tiles 0 and 1 landed (this wave's share)
     __syncthreads();
 
     // transposed-read lane geometry (ds_read_b64_tr_b16, per 16-lane group):
@@ -142,71 +159,43 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
         v_lane[db] = row * 128 + (chunk << 4) + ((tp & 1) << 3);
     }
 
-    int cur = 0, nxt = 2;          // ring stage of tile t / of tile t+2
+    int cur = 0, nxt = NST - 1;    // ring stage of tile t / of the tile issued in iteration t (t + NST - 1)
     for (int t = 0; t < ntiles; ++t) {
-        const bool issued = t + 2 < ntiles;
-        if (issued) ATTN_STAGE_TILE(t + 2, nxt);      // into the stage tile t-1 vacated (everyone passed its barrier)
+        const bool issued = t + NST - 1 < ntiles;
         const uint4* Kb = lds + cur * (2 * TILE_CH);
         const unsigned char* Vb = reinterpret_cast<const unsigned char*>(lds + cur * (2 * TILE_CH) + TILE_CH);
 
         // ---- S^T = K Q^T : two 32-key blocks ----
+        // All eight K fragments are requested before the first MFMA (one LDS round trip exposed per tile instead
+        // of one per MFMA pair), and all V^T fragments of the tile right behind the QK^T MFMAs, so that their latency
+        // runs under the softmax; sched_barriers keep hipcc from sinking the reads back next to their uses.
         f32x16 s0, s1;
+        uint4 kf[8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = 2 * s + hf;
+            const int r0 = lr, r1 = 32 + lr;
+            kf[2 * s] = Kb[r0 * 8 + (ch ^ ((r0 >> 1) & 7))];
+            kf[2 * s + 1] = Kb[r1 * 8 + (ch ^ ((r1 >> 1) & 7))];
+        }
+        if (SDMI_ATTN_HOIST) __builtin_amdgcn_sched_barrier(0);
         {
             f32x16 zero;
 #pragma unroll
             for (int i = 0; i < 16; ++i) zero[i] = 0.f;       // folds into the MFMA's inline-constant C operand
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int ch = 2 * s + hf;
-                const int r0 = lr, r1 = 32 + lr;
-                const uint4 k0 = Kb[r0 * 8 + (ch ^ ((r0 >> 1) & 7))];
-                const uint4 k1 = Kb[r1 * 8 + (ch ^ ((r1 >> 1) & 7))];
-                s0 = mfma32<DT>(k0, qf[s], s == 0 ? zero : s0);
-                s1 = mfma32<DT>(k1, qf[s], s == 0 ? zero : s1);
+                const uint4 qv = __builtin_bit_cast(uint4, qf[s]);
+                s0 = mfma32<DT>(kf[2 * s], qv, s == 0 ? zero : s0);
+                s1 = mfma32<DT>(kf[2 * s + 1], qv, s == 0 ? zero : s1);
             }
         }
-        // accumulator register r of block kb holds key t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hf, query lr
-        if ((t + 1) * KB > p.Nk) {
-            asm volatile("; ragged last tile" ::: "memory");    // keeps this a (uniform) branch, not 96 selects per tile
+        if (SDMI_ATTN_HOIST) __builtin_amdgcn_sched_barrier(0);
+        uint4 vf[2][2][2];       // [kb][ks][db]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * KB + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (key >= p.Nk) s0[r] = -INFINITY;
-                if (key + 32 >= p.Nk) s1[r] = -INFINITY;
-            }
-        }
-        // ---- online softmax (per query = per lane pair (lane, lane^32)) ----
-        float mx = s0[0];
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-        const float mc = m_new * p.c;
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // raw v_exp_f32: arguments are <= 0, a flushed denormal is an exact-enough zero weight
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] * p.c - mc);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] * p.c - mc);
-            psum += s0[r] + s1[r];
-        }
-        l_run = l_run * alpha + psum;     // per-lane partial (this lane's 32 of the 64 keys)
-        m_run = m_new;
-        // rescale the running output only when some query of the wave saw a new maximum (rare after the first tiles)
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-        }
-
-        // ---- O^T += V^T P^T ----
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint4 pf = cvt8<DT>(kb == 0 ? s0 : s1, 8 * ks);
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     // lane part of the address is loop-invariant (v_lane[db]); the rest is an immediate
@@ -219,14 +208,67 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
                     short8v vv;
                     vv[0] = va[0]; vv[1] = va[1]; vv[2] = va[2]; vv[3] = va[3];
                     vv[4] = vc[0]; vv[5] = vc[1]; vv[6] = vc[2]; vv[7] = vc[3];
-                    const uint4 vf = __builtin_bit_cast(uint4, vv);
-                    if (db == 0) o0 = mfma32<DT>(vf, pf, o0);
-                    else         o1 = mfma32<DT>(vf, pf, o1);
+                    vf[kb][ks][db] = __builtin_bit_cast(uint4, vv);
                 }
+        if (SDMI_ATTN_HOIST) __builtin_amdgcn_sched_barrier(0);
+        // tile t+2 into the stage tile t-1 vacated (everyone passed its barrier); issued here, behind the MFMAs, so
+        // that the scalar set-up of the DMA fills the wait states before the accumulators can be read
+        if (issued) ATTN_STAGE_TILE(t + NST - 1, nxt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = fmaf(s0[r], p.c, nm); s1[r] = fmaf(s1[r], p.c, nm); }
+        // accumulator register r of block kb holds key t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hf, query lr
+        if ((t + 1) * KB > p.Nk) {
+            asm volatile("; ragged last tile" ::: "memory");    // keeps this a (uniform) branch, not 96 selects per tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * KB + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (key >= p.Nk) s0[r] = -INFINITY;
+                if (key + 32 >= p.Nk) s1[r] = -INFINITY;
             }
         }
-        if (issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile t+1 landed, tile t+2 may still fly
-        else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- online softmax (per query = per lane pair (lane, lane^32)); s = logit - running max, log2 units ----
+        float mx = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // Move the running maximum (and rescale O, l) only on the first tile or when some query of the wave tops it
+        // by more than 2^RESCALE_THR: a wave-uniform, rare branch.  Otherwise p = 2^s <= 2^RESCALE_THR as it stands.
+        if (t == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
+            asm volatile("; move the running maximum" ::: "memory");
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+            nm -= delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s0[i] -= delta; s1[i] -= delta;
+                o0[i] *= alpha; o1[i] *= alpha;
+            }
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // raw v_exp_f32: a flushed denormal is an exact-enough zero weight
+            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+            psum += s0[r] + s1[r];
+        }
+        l_run += psum;                    // per-lane partial (this lane's 32 of the 64 keys)
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 pf = cvt8<DT>(kb == 0 ? s0 : s1, 8 * ks);
+                o0 = mfma32<DT>(vf[kb][ks][0], pf, o0);
+                o1 = mfma32<DT>(vf[kb][ks][1], pf, o1);
+            }
+        }
+        if (NST == 3 && issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile t+1 landed, tile t+2 may still fly
+        else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur = cur == NST - 1 ? 0 : cur + 1;
         nxt = nxt == NST - 1 ? 0 : nxt + 1;
@@ -271,10 +313,9 @@ extern "C" int sdmi_attention_d64(const void* q, const void* k, const void* v, v
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.c = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)((Nq + QB - 1) / QB), (unsigned)(nb * heads));
-    if (dtype == SDMI_DTYPE_F16)
-        hipLaunchKernelGGL(attn_fwd_d64_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(attn_fwd_d64_kernel<0>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SDMI_DTYPE_F16) hipLaunchKernelGGL(attn_fwd_d64_kernel<1>, grid, dim3(256), 0, hs, a);
+    else                         hipLaunchKernelGGL(attn_fwd_d64_kernel<0>, grid, dim3(256), 0, hs, a);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDMI_LIB") or os.path.join(_HERE, "csrc", "libsdmi_hip.so")
 
 SDMI_OK = 0
-DTYPE_BF16, DTYPE_F16 = 0, 1
+DTYPE_BF16, DTYPE_F16, DTYPE_F32_PLANES = 0, 1, 2
 
 
 class SdmiError(RuntimeError):
@@ -43,7 +43,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 4     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 5     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -65,6 +65,17 @@ SIGNATURES = {
     "sdmi_gemm_tile_m": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32]),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "sdmi_pack_tile_n": (_i32, [_i64, _i32]),
+    "sdmi_pack_linear_k": (_i64, [_i64, _i32]),
+    "sdmi_pack_conv3x3_cin": (_i64, [_i64, _i32]),
+    "sdmi_pack_conv3x3_k": (_i64, [_i64, _i32]),
+    "sdmi_pack_bytes": (_i64, [_i64, _i64, _i32]),
+    "sdmi_pack_linear": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _i32, _i32, _vp]),
+    "sdmi_pack_geglu": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp]),
+    "sdmi_pack_conv3x3": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _vp]),
+    "sdmi_pack_linear_host": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _i32, _i32]),
+    "sdmi_pack_geglu_host": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i32]),
+    "sdmi_pack_conv3x3_host": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32]),
     "sdmi_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _vp, _i64, _vp]),
     "sdmi_groupnorm_workspace_bytes": (_i64, [_i32, _i64]),
     "sdmi_groupnorm_noalloc": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _vp]),

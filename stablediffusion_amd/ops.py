@@ -69,34 +69,7 @@ class PackedWeight:
         self.cin = cin          # conv3x3: (padded) input channels
 
 
-def _tile_n_for(n, geglu=False):
-    """160-column tiles where they divide the width (all SD UNet widths: 320, 640, 960, 1280, 1920, ...):
-    no padded columns and more MFMA work per barrier.  GEGLU pairs 16-column blocks, which needs 128."""
-    return 160 if (n % 160 == 0 and not geglu) else _BN
-
-
-def _pad_pack(w2d, dtype=BF16, tile_n=_BN):
-    n, k = w2d.shape
-    out = torch.zeros(_round_up(n, tile_n), _round_up(k, _BK), dtype=dtype, device=w2d.device)
-    out[:n, :k] = w2d.to(dtype)
-    return out
-
-
 _SPLIT_PAD = 32       # fp32 mode: plane width padding (6 * 32 = 3 GEMM k-tiles, and a conv tap never straddles a k-tile)
-
-
-def _split_planes(w):
-    """fp32 [..., K] -> bf16 [..., 6, Kp]: weight planes (w0 w1 w0 w2 w1 w0) matching the activation planes
-    (x0 x0 x1 x0 x1 x2) of sdmi_f32_split3, with w = w0 + w1 + w2 exactly."""
-    k = w.shape[-1]
-    kp = _round_up(k, _SPLIT_PAD)
-    wz = torch.zeros(*w.shape[:-1], kp, dtype=torch.float32, device=w.device)
-    wz[..., :k] = w
-    w0 = wz.to(BF16)
-    r1 = wz - w0.float()
-    w1 = r1.to(BF16)
-    w2 = (r1 - w1.float()).to(BF16)
-    return torch.stack([w0, w1, w0, w2, w1, w0], dim=-2), kp
 
 
 def split3(x, cp, x2=None):
@@ -111,66 +84,99 @@ def split3(x, cp, x2=None):
     return out
 
 
+# The packers below are thin callers of the C ABI's sdmi_pack_* (csrc/sdmi_pack.hip): a device kernel for weights that
+# live on the GPU, the same arithmetic compiled for the host (sdmi_pack_*_host) for CPU tensors.  torch only supplies
+# the memory.
+
+
+def _pack_dt(dtype):
+    """(sdmi dtype code, torch dtype of the packed buffer)."""
+    if dtype == torch.float32:
+        return hip.DTYPE_F32_PLANES, BF16
+    return _dt(dtype), dtype
+
+
+def _src(t):
+    """fp32, contiguous, detached view / copy of a weight (no arithmetic)."""
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _pack_alloc(rows_total, kp, tile_n, tdt, device):
+    nbytes = hip.lib().sdmi_pack_bytes(rows_total, kp, tile_n)
+    out = torch.empty(nbytes // (2 * kp), kp, dtype=tdt, device=device)
+    return out
+
+
+def _pack_rows(ws, out, code, tile_n):
+    """Pack the [N_i, K] fp32 matrices `ws` one below the other into `out` (sdmi_pack_linear / _host)."""
+    lib = hip.lib()
+    rows_total = sum(w.shape[0] for w in ws)
+    off = 0
+    for w in ws:
+        n, k = w.shape
+        if w.is_cuda:
+            st = lib.sdmi_pack_linear(_p(w), n, k, k, off, rows_total, _p(out), code, tile_n, _stream())
+        else:
+            st = lib.sdmi_pack_linear_host(_p(w), n, k, k, off, rows_total, _p(out), code, tile_n)
+        hip.check(st, "sdmi_pack_linear")
+        off += n
+
+
 def pack_linear(weight, bias=None, dtype=BF16, tile_n=None):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
-    w = weight.detach().reshape(weight.shape[0], -1).float()
-    b = bias.detach().float().contiguous() if bias is not None else None
-    tn = tile_n or _tile_n_for(w.shape[0])
-    if dtype == torch.float32:
-        planes, kp = _split_planes(w)
-        packed = _pad_pack(planes.reshape(w.shape[0], 6 * kp), BF16, tn)
-        return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn, split_cp=kp)
-    packed = _pad_pack(w, dtype, tn)
-    return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn)
+    return pack_linear_cat([weight], None if bias is None else [bias], dtype=dtype, tile_n=tile_n)
 
 
 def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None):
     """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections)."""
-    w = torch.cat([x.detach().reshape(x.shape[0], -1).float() for x in weights], dim=0)
-    b = None
-    if biases is not None:
-        b = torch.cat([x.detach().float() for x in biases]).contiguous()
-    tn = tile_n or _tile_n_for(w.shape[0])
-    if dtype == torch.float32:
-        planes, kp = _split_planes(w)
-        packed = _pad_pack(planes.reshape(w.shape[0], 6 * kp), BF16, tn)
-        return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn, split_cp=kp)
-    packed = _pad_pack(w, dtype, tn)
-    return PackedWeight(packed, b, w.shape[0], packed.shape[1], tile_n=tn)
+    ws = [_src(x.reshape(x.shape[0], -1)) for x in weights]
+    n = sum(w.shape[0] for w in ws)
+    k = ws[0].shape[1]
+    b = torch.cat([_src(x) for x in biases]).contiguous() if biases is not None else None
+    code, tdt = _pack_dt(dtype)
+    tn = tile_n or hip.lib().sdmi_pack_tile_n(n, 0)
+    kp = hip.lib().sdmi_pack_linear_k(k, code)
+    out = _pack_alloc(n, kp, tn, tdt, ws[0].device)
+    _pack_rows(ws, out, code, tn)
+    return PackedWeight(out, b, n, kp, tile_n=tn, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0)
 
 
 def pack_geglu(weight, bias, dtype=BF16):
     """GEGLU projection [2*inner, K]: rows [0,inner) = value, [inner,2*inner) = gate (attention.py:89).
     Packed row r holds value (half 0) or gate (half 1) column blk*16+i with blk=r//32, half=(r%32)//16, i=r%16."""
-    w = weight.detach().float()
-    inner = w.shape[0] // 2
+    w = _src(weight)
+    inner, k = w.shape[0] // 2, w.shape[1]
     assert inner % 16 == 0
-    r = torch.arange(2 * inner, device=w.device)
-    src = ((r % 32) // 16) * inner + (r // 32) * 16 + (r % 16)
-    b = bias.detach().float()[src].contiguous() if bias is not None else None
-    if dtype == torch.float32:
-        planes, kp = _split_planes(w[src])
-        packed = _pad_pack(planes.reshape(2 * inner, 6 * kp), BF16)
-        return PackedWeight(packed, b, inner, packed.shape[1], geglu=True, split_cp=kp)
-    packed = _pad_pack(w[src], dtype)
-    return PackedWeight(packed, b, inner, packed.shape[1], geglu=True)
+    code, tdt = _pack_dt(dtype)
+    kp = hip.lib().sdmi_pack_linear_k(k, code)
+    out = _pack_alloc(2 * inner, kp, _BN, tdt, w.device)
+    b = _src(bias) if bias is not None else None
+    bo = torch.empty_like(b) if b is not None else None
+    if w.is_cuda:
+        st = hip.lib().sdmi_pack_geglu(_p(w), _p(b), inner, k, k, _p(out), _p(bo), code, _stream())
+    else:
+        st = hip.lib().sdmi_pack_geglu_host(_p(w), _p(b), inner, k, k, _p(out), _p(bo), code)
+    hip.check(st, "sdmi_pack_geglu")
+    return PackedWeight(out, bo, inner, kp, geglu=True, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0)
 
 
 def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
-    """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8."""
-    w = weight.detach().float()
+    """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8 (fp32 mode: six planes
+    of ci padded to 32 inside every tap)."""
+    w = _src(weight)
     cout, cin = w.shape[0], w.shape[1]
-    tn = tile_n or _tile_n_for(cout)
-    b = bias.detach().float().contiguous() if bias is not None else None
-    if dtype == torch.float32:
-        planes, cp = _split_planes(w.permute(0, 2, 3, 1))              # [cout, 3, 3, 6, cp]: six planes inside every tap
-        packed = _pad_pack(planes.reshape(cout, 9 * 6 * cp), BF16, tn)
-        return PackedWeight(packed, b, cout, packed.shape[1], cin=6 * cp, tile_n=tn, split_cp=cp)
-    cin_p = _round_up(cin, 8)
-    wp = torch.zeros(cout, 3, 3, cin_p, dtype=torch.float32, device=w.device)
-    wp[..., :cin] = w.permute(0, 2, 3, 1)
-    packed = _pad_pack(wp.reshape(cout, 9 * cin_p), dtype, tn)
-    return PackedWeight(packed, b, cout, packed.shape[1], cin=cin_p, tile_n=tn)
+    code, tdt = _pack_dt(dtype)
+    tn = tile_n or hip.lib().sdmi_pack_tile_n(cout, 0)
+    kp = hip.lib().sdmi_pack_conv3x3_k(cin, code)
+    cin_p = hip.lib().sdmi_pack_conv3x3_cin(cin, code)
+    out = _pack_alloc(cout, kp, tn, tdt, w.device)
+    if w.is_cuda:
+        st = hip.lib().sdmi_pack_conv3x3(_p(w), cout, cin, _p(out), code, tn, _stream())
+    else:
+        st = hip.lib().sdmi_pack_conv3x3_host(_p(w), cout, cin, _p(out), code, tn)
+    hip.check(st, "sdmi_pack_conv3x3")
+    b = _src(bias) if bias is not None else None
+    return PackedWeight(out, b, cout, kp, cin=cin_p, tile_n=tn, split_cp=cin_p // 6 if dtype == torch.float32 else 0)
 
 
 # ----------------------------------------------------------------------------- GEMM family

@@ -221,6 +221,67 @@ def test_weight_packing_layouts():
     assert ops._auto_split_k(65536, 320, 2880) == 1 and ops._auto_split_k(128, 1280, 23040) >= 8
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_c_packers_match_the_torch_reference_bit_for_bit(dtype):
+    """sdmi_pack_*_host (the C ABI's packers, host twins of the device kernels) against tests/ref_pack.py - the torch
+    packers this package used before - on shapes that exercise every padding: K not a multiple of 64 / 32, N not a
+    multiple of the tile, the 160-column tile, Cin = 4 (latent) / 3 (image), concatenation along N, GEGLU with and
+    without bias.  fp32 = the six-plane form of the fp32 mode."""
+    from stablediffusion_amd import ops
+    from tests import ref_pack as R
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g) * 0.7
+
+    def same(pw, ref):
+        assert pw.w.shape == ref.shape and pw.w.dtype == ref.dtype
+        assert torch.equal(pw.w.view(torch.int16), ref.view(torch.int16))
+
+    for n, k, tn in ((40, 24, None), (320, 320, None), (320, 320, 128), (1000, 72, None), (8, 1024, None), (130, 200, 160)):
+        w, b = rnd(n, k), rnd(n)
+        pw = ops.pack_linear(w, b, dtype=dtype, tile_n=tn)
+        same(pw, R.pack_linear_cat([w], dtype, tn))
+        assert torch.equal(pw.bias, b) and pw.n_out == n and pw.k == pw.w.shape[1]
+        assert pw.tile_n == (tn or R.tile_n_for(n))
+        if dtype == torch.float32:
+            assert pw.split_cp == (k + 31) // 32 * 32 and pw.dtype == torch.bfloat16
+    ws = [rnd(320, 96), rnd(320, 96), rnd(17, 96)]
+    same(ops.pack_linear_cat(ws, dtype=dtype), R.pack_linear_cat(ws, dtype))
+    w4 = rnd(64, 48, 1, 1)                                  # conv1x1 weights take the linear path
+    same(ops.pack_linear(w4, dtype=dtype), R.pack_linear_cat([w4], dtype))
+    for inner, k, with_bias in ((64, 64, True), (1280, 320, True), (48, 40, False)):
+        w, b = rnd(2 * inner, k), (rnd(2 * inner) if with_bias else None)
+        pg = ops.pack_geglu(w, b, dtype=dtype)
+        ref_w, ref_b = R.pack_geglu(w, b, dtype)
+        same(pg, ref_w)
+        assert pg.geglu and pg.n_out == inner and pg.tile_n == 128
+        assert (pg.bias is None) == (ref_b is None) and (ref_b is None or torch.equal(pg.bias, ref_b))
+    for cout, cin, tn in ((40, 24, None), (320, 4, None), (3, 128, None), (8, 3, None), (160, 40, 128), (512, 64, None)):
+        w = rnd(cout, cin, 3, 3)
+        pc = ops.pack_conv3x3(w, rnd(cout), dtype=dtype, tile_n=tn)
+        same(pc, R.pack_conv3x3(w, dtype, tn))
+        assert pc.cin == (6 * ((cin + 31) // 32 * 32) if dtype == torch.float32 else (cin + 7) // 8 * 8)
+
+
+def test_c_packer_argument_checks():
+    from stablediffusion_amd import hip
+    import ctypes as C
+    lib = hip.lib()
+    w = torch.zeros(4, 8)
+    out = torch.zeros(128, 64, dtype=torch.int16)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.sdmi_pack_linear_host(p(w), 4, 8, 8, 0, 4, p(out), 0, 128) == 0
+    assert lib.sdmi_pack_linear_host(None, 4, 8, 8, 0, 4, p(out), 0, 128) == -1
+    assert lib.sdmi_pack_linear_host(p(w), 4, 8, 8, 0, 4, p(out), 0, 96) == -1            # tile_n must be 128 | 160
+    assert lib.sdmi_pack_linear_host(p(w), 4, 8, 4, 0, 4, p(out), 0, 128) == -1           # ld_w < K
+    assert lib.sdmi_pack_linear_host(p(w), 4, 8, 8, 2, 4, p(out), 0, 128) == -1           # rows past rows_total
+    assert lib.sdmi_pack_geglu_host(p(w), None, 2, 8, 8, p(out), None, 0) == -1           # inner % 16
+    assert lib.sdmi_pack_bytes(320, 320, 160) == 320 * 320 * 2 and lib.sdmi_pack_bytes(321, 64, 160) == 480 * 64 * 2
+    assert lib.sdmi_pack_tile_n(320, 0) == 160 and lib.sdmi_pack_tile_n(320, 1) == 128 and lib.sdmi_pack_tile_n(512, 0) == 128
+    assert lib.sdmi_pack_linear_k(320, 0) == 320 and lib.sdmi_pack_linear_k(72, 1) == 128 and lib.sdmi_pack_linear_k(40, 2) == 384
+    assert lib.sdmi_pack_conv3x3_cin(4, 0) == 8 and lib.sdmi_pack_conv3x3_cin(4, 2) == 192
+    assert lib.sdmi_pack_conv3x3_k(4, 0) == 128 and lib.sdmi_pack_conv3x3_k(320, 0) == 2880
+
+
 def test_dp_shard_ranges():
     from stablediffusion_amd import dp
     for gb, world in ((64, 8), (10, 4), (3, 8), (0, 2)):

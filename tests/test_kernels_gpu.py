@@ -330,6 +330,76 @@ def test_attention_fused_qkv_and_spike(dev):
     assert rel_err(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_device_packers_equal_host_packers_and_feed_gemm(dev, dtype):
+    """sdmi_pack_* (device kernels) produce the same bits as sdmi_pack_*_host (pinned on the CPU against the torch
+    reference, tests/test_host_cpu.py), and sdmi_gemm computes the right products from buffers packed entirely through
+    the C ABI - no torch arithmetic between the fp32 weight and the kernel."""
+    ops = _ops()
+    same = lambda a, b: a.w.shape == b.w.shape and torch.equal(a.w.view(torch.int16).cpu(), b.w.view(torch.int16))
+    w, b = rnd((332, 200), dev, 1), rnd((332,), dev, 2)
+    assert same(ops.pack_linear(w, b, dtype=dtype), ops.pack_linear(w.cpu(), b.cpu(), dtype=dtype))
+    ws = [rnd((320, 96), dev, 3), rnd((320, 96), dev, 4), rnd((17, 96), dev, 5)]
+    assert same(ops.pack_linear_cat(ws, dtype=dtype), ops.pack_linear_cat([t.cpu() for t in ws], dtype=dtype))
+    wg, bg = rnd((2 * 96, 72), dev, 6), rnd((2 * 96,), dev, 7)
+    pg_d, pg_h = ops.pack_geglu(wg, bg, dtype=dtype), ops.pack_geglu(wg.cpu(), bg.cpu(), dtype=dtype)
+    assert same(pg_d, pg_h) and torch.equal(pg_d.bias.cpu(), pg_h.bias)
+    wc = rnd((40, 12, 3, 3), dev, 8)
+    assert same(ops.pack_conv3x3(wc, dtype=dtype), ops.pack_conv3x3(wc.cpu(), dtype=dtype))
+    # products from C-packed weights
+    f32 = dtype == torch.float32
+    cast = (lambda t: t) if f32 else (lambda t: t.to(dtype))
+    qd = (lambda t: t) if f32 else (lambda t: t.to(dtype).float())
+    tol = 2e-5 if f32 else 6e-3
+    x = rnd((70, 200), dev, 9)
+    out = ops.linear(cast(x), ops.pack_linear(w, b, dtype=dtype), out_dtype=torch.float32)
+    assert rel_err(out, F.linear(qd(x), qd(w), b)) < tol
+    xg = rnd((50, 72), dev, 10)
+    og = ops.linear(cast(xg), pg_d, out_dtype=torch.float32)
+    a_, g_ = F.linear(qd(xg), qd(wg), bg).chunk(2, dim=-1)
+    assert rel_err(og, a_ * F.gelu(g_)) < tol
+    xi = rnd((2, 12, 9, 7), dev, 11)
+    xin = xi.permute(0, 2, 3, 1).contiguous()
+    if not f32:
+        xin = torch.cat([xin, torch.zeros(2, 9, 7, 4, device=dev)], dim=-1).to(dtype)     # Cin 12 -> the packed 16
+    oc = ops.conv3x3(xin, ops.pack_conv3x3(wc, rnd((40,), dev, 12), dtype=dtype), out_nchw_f32=True)
+    assert rel_err(oc, F.conv2d(qd(xi), qd(wc), rnd((40,), dev, 12), padding=1)) < tol
+
+
+LN2, LOG2E = 0.6931471805599453, 1.4426950408889634
+
+
+@pytest.mark.parametrize("dt", [torch.float16, BF16])
+@pytest.mark.parametrize("case", ["random", "spike_late", "spike_early", "all_negative", "ragged"])
+def test_attention_lazy_rescale_branches(dev, dt, case):
+    """The running maximum only moves when a tile tops it by 2^8 (a rare, wave-uniform branch).  Cases force each
+    branch: a key that dominates late (rescale by a large factor mid-sequence) or in the first tile (no later rescale,
+    everything else underflows), logits that are all far below zero (the first tile must still anchor the maximum or
+    f16 probabilities underflow), ragged Nk; each with the logit scale passed in and with the scale folded into q
+    (scale = ln 2: logits arrive in log2 units)."""
+    ops = _ops()
+    nb, heads, nq, nk = (1, 2, 256, 512) if case != "ragged" else (2, 3, 200, 333)
+    c = heads * 64
+    qq, kk, vv = rnd((nb * nq, c), dev, 11), rnd((nb * nk, c), dev, 12), rnd((nb * nk, c), dev, 13)
+    if case == "spike_late":
+        kk[300] *= 12.0
+        qq[5, :] = kk[300] / 12.0
+    elif case == "spike_early":
+        kk[3] *= 12.0
+        qq[7, :] = kk[3] / 12.0
+    elif case == "all_negative":
+        kk[:] = kk[:1] * 3.0 + 0.05 * kk          # all keys nearly parallel ...
+        qq[:] = -kk[:1] * 3.0 + 0.05 * qq         # ... and every query anti-parallel to them: logits ~ -70
+    qs = (qq * (0.125 * LOG2E)).to(dt)              # the fold happens in fp32, then ONE rounding to the operand type
+    out = ops.attention_d64(qs, kk.to(dt), vv.to(dt), heads, nb, nq, nk, LN2)
+    ref = _attn_ref(qs.float(), kk.to(dt).float(), vv.to(dt).float(), nb, heads, nq, nk, LN2)
+    assert bool(torch.isfinite(out.float()).all())
+    assert rel_err(out, ref) < (1e-2 if dt == BF16 else 2e-3), case
+    # and the general path (scale passed in, no fold) gives the same attention up to the operand rounding of q
+    out2 = ops.attention_d64(qq.to(dt), kk.to(dt), vv.to(dt), heads, nb, nq, nk, 0.125)
+    assert rel_err(out2, ref) < (3e-2 if dt == BF16 else 6e-3), case
+
+
 def test_softmax_rows_cols(dev):
     ops = _ops()
     s = rnd((2, 300, 512), dev, 1) * 4

@@ -21,7 +21,7 @@ SHAPES = [  # kind, args
 SHAPES += [("conv", (16, 16, 16, 2560, 1280)), ("conv", (16, 8, 8, 2560, 1280)), ("conv", (16, 32, 32, 1280, 640)),
            ("conv", (16, 64, 64, 960, 320))]
 SHAPES += [("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
-auto_split, auto_tile = ops._auto_split_k, ops._tile_n_for
+auto_split = ops._auto_split_k
 configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
 if os.environ.get("SWEEP"):
     configs = [(None, s, tm) for tm in ("128", "129", "256") for s in (None, "1", "2", "4")]
@@ -29,12 +29,12 @@ for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in confi
     ops.FORCE_TILE_M = int(tile_m)
     if only and only != kind:
         continue
-    ops._tile_n_for = (lambda n, geglu=False: 128) if tile == "128" else auto_tile
+    tn = 128 if tile == "128" else None
     ops._auto_split_k = (lambda m, n, k, t=128, s_=split: min(int(s_), k // 128)) if split else auto_split
     if kind == "conv":
         b, h, w, cin, cout = a
         x = torch.randn(b, h, w, cin, device=dev).to(BF16)
-        pw = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, torch.randn(cout, device=dev))
+        pw = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, torch.randn(cout, device=dev), tile_n=tn)
         fn = lambda: ops.conv3x3(x, pw)
         flops = 2 * b * h * w * cout * 9 * cin
     elif kind == "geglu":
@@ -46,7 +46,7 @@ for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in confi
     else:
         m, n, k = a
         x = torch.randn(m, k, device=dev).to(BF16)
-        pw = ops.pack_linear(torch.randn(n, k, device=dev) * 0.02, torch.randn(n, device=dev))
+        pw = ops.pack_linear(torch.randn(n, k, device=dev) * 0.02, torch.randn(n, device=dev), tile_n=tn)
         res = torch.randn(m, n, device=dev).to(BF16)
         fn = lambda: ops.linear(x, pw, res=res)
         flops = 2 * m * n * k
