@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -197,7 +197,25 @@ int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                        float scale, int32_t dtype, void* stream);
 
-/* Row / column softmax helpers for the VAE single-head attention (model.py:514-523), whose
+/* ------------------------------------------------------------------------------------------
+ * Single-head attention of the VAE's AttnBlock (ldm/modules/diffusion/model.py:514-525: the bmm / softmax / bmm chain
+ * on [B, N, C] with C = 512), head dim D in {64, 128, 256, 512}, 16-bit in/out, fp32 logits and softmax, WITHOUT the
+ * [B, N, N] score tensor the reference materialises (340 MB per image at 768^2).
+ *   W[i, j] = softmax_j( scale * q_i . k_j )
+ *   mode 0 ("standard", upstream):  out[b, i, :] = sum_j W[i, j] v[b, j, :]
+ *   mode 1 ("reference", literally model.py:519-523 - the contraction runs over the QUERY index):
+ *                                    out[b, j, :] = sum_i W[i, j] v[b, i, :]
+ * Two launches (row statistics, then the weighted sum with the logits recomputed): 6 N^2 D FLOP.
+ * q, k, v: [nb * N, ld*] rows, out likewise; leading dimensions multiples of 8 (ldo: 4); N even.
+ * workspace: sdmi_attention_vae_workspace_bytes(nb, N) bytes (two floats per query).
+ * ---------------------------------------------------------------------------------------- */
+int sdmi_attention_vae(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t N, int32_t D,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int32_t mode, int32_t dtype,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+int64_t sdmi_attention_vae_workspace_bytes(int32_t nb, int32_t N);
+
+/* Row / column softmax helpers (the three-GEMM form of the VAE attention that sdmi_attention_vae replaced; kept for
+ * callers that want the probabilities themselves) (model.py:514-523), whose
  * score matrix S is produced by sdmi_gemm (out_kind 1).
  *   rows: P[i, j] = softmax_j S[i, j]            (16-bit out)     - "standard" mode
  *   cols: PT[j, i] = softmax_j ST[j, i] for each column i of ST    - "reference" mode, where

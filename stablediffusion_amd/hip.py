@@ -43,7 +43,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 5     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 6     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -81,6 +81,8 @@ SIGNATURES = {
     "sdmi_groupnorm_noalloc": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _vp]),
     "sdmi_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "sdmi_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _i32, _vp]),
+    "sdmi_attention_vae": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _i32, _i32, _vp, _i64, _vp]),
+    "sdmi_attention_vae_workspace_bytes": (_i64, [_i32, _i32]),
     "sdmi_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "sdmi_softmax_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp]),
     "sdmi_softmax_cols_scratch_bytes": (_i64, [_i32, _i64]),

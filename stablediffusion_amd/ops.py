@@ -489,6 +489,26 @@ def attention_d64(q, k, v, heads, nb, nq, nk, scale, causal=False):
     return out
 
 
+def attention_vae(q, k, v, nb, n, scale, mode):
+    """Single-head attention over [nb*n, D] 16-bit matrices (row strides from the tensors, inner stride 1):
+    mode "standard" = softmax(QK^T) V, "reference" = the reference's contraction over the query index
+    (model.py:519-523).  Two launches, no [nb, n, n] tensor (sdmi_attention_vae)."""
+    d = q.shape[-1]
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dtype != q.dtype or not t.is_cuda or t.stride(-1) != 1 or t.shape[-1] != d or t.dim() != 2:
+            raise hip.SdmiError(f"attention_vae: bad {name}")
+    if mode not in ("standard", "reference"):
+        raise ValueError(f"vae_attn must be 'reference' or 'standard', got {mode!r}")
+    dt = _dt(q.dtype)
+    out = torch.empty(nb * n, d, dtype=q.dtype, device=q.device)
+    nbytes = hip.lib().sdmi_attention_vae_workspace_bytes(nb, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    hip.check(hip.lib().sdmi_attention_vae(_p(q), _p(k), _p(v), _p(out), nb, n, d, q.stride(0), k.stride(0), v.stride(0),
+                                           out.stride(0), scale, 1 if mode == "reference" else 0, dt, _p(ws), nbytes,
+                                           _stream()), "sdmi_attention_vae")
+    return out
+
+
 def embed_tokens(ids, table, pos):
     """ids int64 [B, T] -> fp32 [B, T, C] = table[ids] + pos  (token + positional embedding)."""
     _require(table, torch.float32, "table")

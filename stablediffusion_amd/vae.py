@@ -64,17 +64,6 @@ class DownSample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, 3, stride=2, padding=0)
 
 
-def _pad_rows(t, mult):
-    """[Z, R, K] -> rows padded with zeros to a multiple of `mult` (only tiny test shapes need it)."""
-    r = t.shape[1]
-    rp = (r + mult - 1) // mult * mult
-    if rp == r:
-        return t
-    out = torch.zeros(t.shape[0], rp, t.shape[2], dtype=t.dtype, device=t.device)
-    out[:, :r] = t
-    return out
-
-
 class _VaeNet(nn.Module):
     """What Encoder and Decoder share on the HIP path: weight packing, ResnetBlock, AttnBlock, dtype policy."""
 
@@ -115,9 +104,7 @@ class _VaeNet(nn.Module):
                 c = m.in_channels
                 pk[id(m)] = {
                     "gn": (f32(m.norm.weight), f32(m.norm.bias)),
-                    "q": ops.pack_linear(m.q.weight, m.q.bias, dtype=cd), "k": ops.pack_linear(m.k.weight, m.k.bias, dtype=cd),
-                    # V^T = Wv . Xn^T needs Wv as the (unpadded-row) A operand and its bias per row
-                    "wv": m.v.weight.detach().reshape(c, c).to(cd).contiguous()[None], "bv": f32(m.v.bias),
+                    "qkv": ops.pack_linear_cat([m.q.weight, m.k.weight, m.v.weight], [m.q.bias, m.k.bias, m.v.bias], dtype=cd),
                     "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias, dtype=cd),
                 }
             elif isinstance(m, (UpSample, DownSample)):
@@ -137,44 +124,19 @@ class _VaeNet(nn.Module):
         return ops.conv3x3(n2, e["conv2"], res=sk)
 
     def _attn(self, pk, m, h):
+        """AttnBlock.forward (model.py:496-528): GroupNorm -> q | k | v (one GEMM) -> single-head attention (two
+        launches, no [B, N, N] tensor) -> proj_out + residual."""
         e = pk[id(m)]
         b, hh, ww, c = h.shape
         n = hh * ww
-        if c % 64:
-            raise NotImplementedError("VAE attention needs channels % 64 == 0")
-        hn = ops.groupnorm(h, e["gn"][0], e["gn"][1], 1e-6, False).reshape(b, n, c)
-        q = ops.linear(hn, e["q"])
-        k = ops.linear(hn, e["k"])
-        scale = float(int(c) ** (-0.5))
-        hn_p = _pad_rows(hn, 128)
-        npad = hn_p.shape[1]
-        cd = self.compute_dtype
-        vt = ops.gemm_nt_batched(e["wv"], hn_p, cd, bias_rows=e["bv"])       # [b, c, npad]: V^T (+bias per channel)
-        if npad != n:
-            vt[:, :, n:] = 0
-        if self.vae_attn == "reference":
-            # ST[j, i] = scale * k_j . q_i ; PT[j, i] = W[i, j] (softmax over j) ; O[j, :] = sum_i PT[j, i] V[i, :]
-            st = ops.gemm_nt_batched(k, _pad_rows(q, 128), torch.float32, alpha=scale)[:, :, :n].contiguous() \
-                if npad != n else ops.gemm_nt_batched(k, q, torch.float32, alpha=scale)
-            pt = ops.softmax_cols(st, cd)
-        elif self.vae_attn == "standard":
-            st = ops.gemm_nt_batched(q, _pad_rows(k, 128), torch.float32, alpha=scale)[:, :, :n].contiguous() \
-                if npad != n else ops.gemm_nt_batched(q, k, torch.float32, alpha=scale)
-            pt = ops.softmax_rows(st, cd)
-        else:
+        if self.vae_attn not in ("reference", "standard"):
             raise ValueError(f"vae_attn must be 'reference' or 'standard', got {self.vae_attn!r}")
-        if n % 64:
-            raise NotImplementedError("VAE attention needs h*w % 64 == 0")
-        if npad != n:   # K (= token count) of the last product must match between P and V^T
-            ptp = torch.zeros(b, n, npad, dtype=cd, device=h.device)
-            ptp[:, :, :n] = pt
-            pt = ptp
-        cp = (c + 127) // 128 * 128
-        vt_p = _pad_rows(vt, 128) if cp != c else vt
-        o = ops.gemm_nt_batched(pt, vt_p, cd)[:, :, :c]
-        if cp != c:
-            o = o.contiguous()
-        out = ops.linear(o.reshape(b * n, c), e["proj"], res=h.reshape(b * n, c))
+        if c not in (64, 128, 256, 512) or n % 2:
+            raise NotImplementedError("VAE attention is built for 64 / 128 / 256 / 512 channels and an even token count")
+        hn = ops.groupnorm(h, e["gn"][0], e["gn"][1], 1e-6, False).reshape(b * n, c)
+        qkv = ops.linear(hn, e["qkv"])
+        o = ops.attention_vae(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, n, float(int(c) ** (-0.5)), self.vae_attn)
+        out = ops.linear(o, e["proj"], res=h.reshape(b * n, c))
         return out.reshape(b, hh, ww, c)
 
 

@@ -400,6 +400,42 @@ def test_attention_lazy_rescale_branches(dev, dt, case):
     assert rel_err(out2, ref) < (3e-2 if dt == BF16 else 6e-3), case
 
 
+@pytest.mark.parametrize("dt", [torch.float16, BF16])
+@pytest.mark.parametrize("nb,n,d", [(2, 256, 128), (1, 1024, 512), (9, 64, 512), (1, 50, 64), (2, 330, 256), (1, 4096, 512)])
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+def test_attention_vae(dev, dt, nb, n, d, mode):
+    """sdmi_attention_vae (VAE AttnBlock, one head of dim d) against the fp32 formulas of model.py:514-525 on the
+    rounded operands: standard = softmax(QK^T) V; reference = W^T V with W row-normalised over the key index.
+    Shapes: ragged row blocks / contraction tiles (n = 50, 330), nb > 8 (XCD remap tail), the SD2 shape (4096 x 512);
+    q | k | v as column slices of one buffer, as the model passes them."""
+    ops = _ops()
+    qkv = (rnd((nb * n, 3 * d), dev, 21) * 1.5).to(dt)
+    qkv[n // 3, d:2 * d] *= 3.0           # one key with large logits: a peaked row of W
+    out = ops.attention_vae(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], nb, n, d ** -0.5, mode)
+    f = qkv.float().reshape(nb, n, 3 * d)
+    qq, kk, vv = f[..., :d], f[..., d:2 * d], f[..., 2 * d:]
+    w = (torch.einsum("bid,bjd->bij", qq, kk) * d ** -0.5).softmax(-1)
+    ref = torch.einsum("bij,bjd->bid", w, vv) if mode == "standard" else torch.einsum("bij,bid->bjd", w, vv)
+    assert out.shape == (nb * n, d) and bool(torch.isfinite(out.float()).all())
+    assert rel_err(out.reshape(nb, n, d), ref) < (1.2e-2 if dt == BF16 else 2e-3)
+
+
+def test_attention_vae_argument_checks(dev):
+    import ctypes as C
+    from stablediffusion_amd import hip
+    lib = hip.lib()
+    x = torch.zeros(64, 64, dtype=BF16, device=dev)
+    ws = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    call = lambda n, d, mode, wsb: lib.sdmi_attention_vae(p(x), p(x), p(x), p(x), 1, n, d, 64, 64, 64, 64, 0.125, mode, 0,
+                                                          p(ws), wsb, None)
+    assert call(64, 64, 0, 1024) == 0
+    assert call(64, 96, 0, 1024) == -1 and call(64, 64, 2, 1024) == -1      # head dim / mode
+    assert call(63, 64, 0, 1024) == -2                                        # odd token count
+    assert call(64, 64, 0, 100) == -3                                         # workspace
+    torch.cuda.synchronize()
+
+
 def test_softmax_rows_cols(dev):
     ops = _ops()
     s = rnd((2, 300, 512), dev, 1) * 4
