@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -103,6 +103,9 @@ typedef struct sdmi_gemm_args {
     int32_t res_f32;                    /* 1: `res` is fp32 (only with an fp32 out_kind) - the fp32 mode of the path */
     int32_t stages;                     /* LDS ring depth: 0 | 3 = three stages; 2 (128-row tile only) = two stages,
                                            two blocks per CU - for short K */
+    int32_t algo;                       /* 0 = the library picks; 1 = the tiled kernel; 2 = the A-panel-stationary kernel
+                                           (mode 0, K == 320, 16-bit output, N_w % 160 == 0 or GEGLU: every workgroup keeps
+                                           its rows of A in LDS and streams all of W) - SDMI_ERR_BAD_ARG if it does not apply */
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);

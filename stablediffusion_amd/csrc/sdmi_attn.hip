@@ -21,7 +21,11 @@
 // Measured and dropped (MI355X, N = 4096): folding scale * log2(e) into the query projection and starting the QK^T
 // accumulator at -m instead of 0, so that a probability is a bare exp2 - 32 fewer VALU per tile, yet 8 % SLOWER
 // (846 against 920 TFLOP/s): an MFMA whose C operand is a VGPR block other than its destination costs more than
-// the fmas it saves.  What did pay (+24 %): keeping hipcc's wait for the Q fragment loads out of the loop (below).
+// the fmas it saves.  Also measured and dropped: a software-pipelined loop (QK^T MFMAs of tile t+1 issued under the
+// softmax VALU of tile t inside one wave, 4-stage ring, 194 VGPRs -> two waves per SIMD): bit-identical results,
+// 8-10 % slower than this kernel at three waves per SIMD (749 against 815 TFLOP/s on the same box) - co-resident
+// waves in complementary phases already provide that overlap, and the third wave is worth more than the pipelining.
+// What did pay (+24 %): keeping hipcc's wait for the Q fragment loads out of the loop (below).
 #include "sdmi_common.h"
 
 #ifndef SDMI_ATTN_OCC
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
         }
     }
 }
+
 
 }  // namespace
 

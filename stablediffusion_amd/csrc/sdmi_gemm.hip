@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
 SDMI_GEMM_UNIT_DECL(m0_bf16) SDMI_GEMM_UNIT_DECL(m0_f16) SDMI_GEMM_UNIT_DECL(m1_bf16) SDMI_GEMM_UNIT_DECL(m1_f16)
 #undef SDMI_GEMM_UNIT_DECL
 
+int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s);      // sdmi_gemm_panel.hip
+
 // Row tile the launcher picks: 256 rows once that still gives every CU a block, else 128 rows.
 static int pick_tile_m(int64_t M, int64_t N_w, int tile_n, int64_t problems) {
     const int bn = tile_n == 160 ? 160 : 128;
@@ -142,6 +144,12 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
             return SDMI_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p.algo < 0 || p.algo > 2) return SDMI_ERR_BAD_ARG;
+    if (p.algo != 1) {       // short K, many rows: the A-panel-stationary kernel (sdmi_gemm_panel.h)
+        const int st = sdmi_gemm_panel_launch(p, s);
+        if (st != 0) return st < 0 ? st : SDMI_OK;
+        if (p.algo == 2) return SDMI_ERR_BAD_ARG;
+    }
     // dynamic-LDS attribute of every instantiation, once per process (thread-safe; a refusal is reported, not ignored)
     static std::once_flag attr_once;
     static int attr_status = SDMI_OK;

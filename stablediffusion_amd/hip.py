@@ -40,10 +40,11 @@ class GemmArgs(C.Structure):
         ("asym_pad", C.c_int32),
         ("res_f32", C.c_int32),
         ("stages", C.c_int32),
+        ("algo", C.c_int32),
     ]
 
 
-ABI_VERSION = 6     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 7     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

@@ -182,6 +182,7 @@ def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
 # ----------------------------------------------------------------------------- GEMM family
 
 
+FORCE_ALGO = 0        # development aid / tests: sdmi_gemm_args.algo (0 auto, 1 tiled kernel, 2 panel kernel)
 FORCE_TILE_M = 0      # development aid (tools/bench_gemm.py): 0 = the library picks the row tile, else 128 | 256
 
 _CUS = 256            # MI355X compute units; the GEMM kernel runs one 8-wave block per CU at a time
@@ -285,6 +286,7 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.ld_res = res.shape[-1]
     n_w = pw.n_out * (2 if pw.geglu else 1)
     a.tile_n = pw.tile_n
+    a.algo = FORCE_ALGO
     a.tile_m, sk, a.stages = _plan_gemm(m, n_w, pw.k, pw.tile_n)
     sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)      # (separate hook: tests and tools pin it)
     if FORCE_TILE_M:

@@ -366,6 +366,65 @@ def test_device_packers_equal_host_packers_and_feed_gemm(dev, dtype):
     assert rel_err(oc, F.conv2d(qd(xi), qd(wc), rnd((40,), dev, 12), padding=1)) < tol
 
 
+@pytest.mark.parametrize("dt", [BF16, torch.float16])
+@pytest.mark.parametrize("m,n,bias,res", [(16384, 320, True, True), (16420, 320, False, False), (16384, 960, False, False),
+                                          (17111, 640, True, True), (20000, 1280, True, False)])
+def test_panel_gemm_k320(dev, dt, m, n, bias, res):
+    """The A-panel-stationary kernel (sdmi_gemm_args.algo = 2; K = 320, every workgroup streams all of W past its
+    resident rows of A) against F.linear on the rounded operands and against the tiled kernel (algo = 1), incl. a
+    ragged last row panel and several column tiles."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    x, w = rnd((m, 320), dev, 31), rnd((n, 320), dev, 32, 0.06)
+    b = rnd((n,), dev, 33) if bias else None
+    r = rnd((m, n), dev, 34) if res else None
+    pw = ops.pack_linear(w, b, dtype=dt)
+    outs = {}
+    for algo in (2, 1):
+        ops.FORCE_ALGO = algo
+        try:
+            outs[algo] = ops.linear(x.to(dt), pw, res=r.to(dt) if res else None)
+        finally:
+            ops.FORCE_ALGO = 0
+    ref = F.linear(qd(x), qd(w), b) + (qd(r) if res else 0)
+    tol = 8e-3 if dt == BF16 else 1.5e-3
+    assert rel_err(outs[2], ref) < tol and rel_err(outs[1], ref) < tol
+    assert rel_err(outs[2], outs[1].float()) < tol
+    auto = ops.linear(x.to(dt), pw, res=r.to(dt) if res else None)       # what the library picks on its own
+    assert torch.equal(auto, outs[2])
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16])
+@pytest.mark.parametrize("m,inner", [(16384, 1280), (16500, 128)])
+def test_panel_gemm_k320_geglu(dev, dt, m, inner):
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    x, w, b = rnd((m, 320), dev, 35), rnd((2 * inner, 320), dev, 36, 0.06), rnd((2 * inner,), dev, 37)
+    pw = ops.pack_geglu(w, b, dtype=dt)
+    outs = {}
+    for algo in (2, 1):
+        ops.FORCE_ALGO = algo
+        try:
+            outs[algo] = ops.linear(x.to(dt), pw)
+        finally:
+            ops.FORCE_ALGO = 0
+    a_, g_ = F.linear(qd(x), qd(w), b).chunk(2, dim=-1)
+    ref = a_ * F.gelu(g_)
+    tol = 8e-3 if dt == BF16 else 1.5e-3
+    assert rel_err(outs[2], ref) < tol and rel_err(outs[1], ref) < tol
+
+
+def test_panel_gemm_refuses_what_it_is_not_built_for(dev):
+    ops = _ops()
+    x, pw = rnd((4096, 640), dev, 38).to(BF16), ops.pack_linear(rnd((640, 640), dev, 39))
+    ops.FORCE_ALGO = 2
+    try:
+        with pytest.raises(ops.hip.SdmiError):
+            ops.linear(x, pw)                     # K = 640
+    finally:
+        ops.FORCE_ALGO = 0
+
+
 LN2, LOG2E = 0.6931471805599453, 1.4426950408889634
 
 

@@ -239,10 +239,16 @@ def test_ddim_trajectory_256(dev, param, dt):
     assert psnr(img, img_ref, float(img_ref.max() - img_ref.min())) >= 35.0
 
 
-def test_plms_matches_oracle(dev):
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_plms_matches_oracle(dev, dt):
+    """PLMS (absent from the reference: restated from upstream semantics, parity unpinned by the reference).
+    (i) teacher-forced: the sampler's multistep arithmetic alone - every model evaluation is answered by the ORACLE's
+    UNet, so the HIP side contributes only the guidance combine (sdmi_lincomb4), the Adams-Bashforth combinations and
+    the x_prev updates (sdmi_ddim_step): the 10-step trajectory must then match the oracle's to fp32 rounding;
+    (ii) free-running with the HIP UNet in the given dtype."""
     from oracle import sampler as OSamp
     from stablediffusion_amd.plms import PLMSSampler
-    model, sd = _latent_diffusion(dev, policy(synth.TINY_UNET, "bf16"), synth.TINY_DDCONFIG)
+    model, sd = _latent_diffusion(dev, policy(synth.TINY_UNET, dt), synth.TINY_DDCONFIG)
     unet_sd = {k[len("model.diffusion_model."):]: v for k, v in sd.items() if k.startswith("model.diffusion_model.")}
     x_T = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5))
     c = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(6))
@@ -251,11 +257,19 @@ def test_plms_matches_oracle(dev):
     with torch.no_grad():
         fn = lambda x, t, cond: OSamp.apply_model(unet_sd, synth.TINY_UNET, x, t, cond)
         ref = OSamp.plms_sample(fn, acp, 10, x_T, c, uc, 5.0)
-    out, _ = PLMSSampler(model).sample(S=10, batch_size=2, shape=[4, 16, 16], conditioning=c.to(dev), verbose=False,
-                                       unconditional_guidance_scale=5.0, unconditional_conditioning=uc.to(dev),
-                                       x_T=x_T.to(dev))
-    print(f"[parity] plms tiny 10-step latent rel_err {rel_err(out, ref):.3e}")
-    assert rel_err(out, ref) < 5e-2
+    kw = dict(S=10, batch_size=2, shape=[4, 16, 16], conditioning=c.to(dev), verbose=False,
+              unconditional_guidance_scale=5.0, unconditional_conditioning=uc.to(dev), x_T=x_T.to(dev))
+    if dt == HEADLINE:
+        forced = PLMSSampler(model)
+        with torch.no_grad():
+            forced._apply = lambda x, t, cond: fn(x.cpu(), t.cpu(), cond.cpu()).to(dev)
+            out_tf, _ = forced.sample(**kw)
+        e_tf = rel_err(out_tf, ref)
+        print(f"[parity] plms tiny 10-step, model evaluations teacher-forced by the oracle: latent rel_err {e_tf:.3e}")
+        assert e_tf < 1e-5
+    out, _ = PLMSSampler(model).sample(**kw)
+    print(f"[parity] plms tiny 10-step free-running ({dt}) latent rel_err {rel_err(out, ref):.3e}")
+    assert rel_err(out, ref) < (5e-2 if dt == "bf16" else 1e-2)
 
 
 def test_plms_hip_graph_without_cfg_matches_eager(dev):

@@ -8,6 +8,7 @@ import torch
 from stablediffusion_amd import ops
 
 dev = torch.device("cuda:0")
+ops.FORCE_ALGO = int(os.environ.get("ALGO", "0"))      # 1 = tiled kernel only, 2 = panel kernel (fails where it does not apply)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else None
 BF16 = torch.bfloat16
@@ -20,14 +21,16 @@ SHAPES = [  # kind, args
 ]
 SHAPES += [("conv", (16, 16, 16, 2560, 1280)), ("conv", (16, 8, 8, 2560, 1280)), ("conv", (16, 32, 32, 1280, 640)),
            ("conv", (16, 64, 64, 960, 320))]
-SHAPES += [("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
+SHAPES += [("linnr", (65536, 960, 320)), ("linnr", (65536, 320, 320)), ("linnr", (16384, 1920, 640)), ("linnr", (16384, 640, 640)),
+           ("lin", (65536, 960, 320)), ("lin", (8192, 320, 320)), ("lin", (147456, 320, 320)),
+           ("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
 auto_split = ops._auto_split_k
 configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
 if os.environ.get("SWEEP"):
     configs = [(None, s, tm) for tm in ("128", "129", "256") for s in (None, "1", "2", "4")]
 for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in configs]:
     ops.FORCE_TILE_M = int(tile_m)
-    if only and only != kind:
+    if only and only != kind and not (only == "lin" and kind == "linnr"):
         continue
     tn = 128 if tile == "128" else None
     ops._auto_split_k = (lambda m, n, k, t=128, s_=split: min(int(s_), k // 128)) if split else auto_split
@@ -47,11 +50,15 @@ for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in confi
         m, n, k = a
         x = torch.randn(m, k, device=dev).to(BF16)
         pw = ops.pack_linear(torch.randn(n, k, device=dev) * 0.02, torch.randn(n, device=dev), tile_n=tn)
-        res = torch.randn(m, n, device=dev).to(BF16)
+        res = torch.randn(m, n, device=dev).to(BF16) if kind == "lin" else None
         fn = lambda: ops.linear(x, pw, res=res)
         flops = 2 * m * n * k
-    for _ in range(3):
-        fn()
+    try:
+        for _ in range(3):
+            fn()
+    except ops.hip.SdmiError as e:
+        print(f"{kind:5s} {str(a):32s} n/a ({e})", flush=True)
+        continue
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
