@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float nm = 0.f, l_run = 0.f;       // nm = -(running maximum), log2 units
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    float nm = 0.f;                    // nm = -(running maximum), log2 units
+    f32x2 l_run = {0.f, 0.f}, l_run1 = {0.f, 0.f};   // running row sum: 2 x 2 partial sums per lane (v_pk_add_f32: 16 adds per
+                                                     // tile instead of 32, in two independent chains)
 
     // ---- staging: wave w issues, per tile, K rows {8w..8w+7, 32+8w..} and the same V rows: 4 DMA instructions ----
     // lane l of an instruction owns physical chunk l&7 of row R = 32*i + 8*w + (l>>3) and fetches the logical chunk
@@ -236,7 +239,13 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        {   // the other half of the query's keys sits on lane ^ 32: v_permlane32_swap (lanes 32..63 of the first operand
+            // <-> lanes 0..31 of the second), no LDS round trip on the critical path.  Inline asm on purpose: with the
+            // builtin, hipcc folds max(result0, result1) of a value swapped with its own copy down to result0.
+            float ma = mx, mb = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+            mx = fmaxf(ma, mb);
+        }
         // Move the running maximum (and rescale O, l) only on the first tile or when some query of the wave tops it
         // by more than 2^RESCALE_THR: a wave-uniform, rare branch.  Otherwise p = 2^s <= 2^RESCALE_THR as it stands.
         if (t == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
@@ -244,22 +253,24 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
             const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
             const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
             nm -= delta;
-            l_run *= alpha;
+            l_run *= alpha; l_run1 *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 s0[i] -= delta; s1[i] -= delta;
                 o0[i] *= alpha; o1[i] *= alpha;
             }
         }
-        float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // raw v_exp_f32: a flushed denormal is an exact-enough zero weight
             s0[r] = __builtin_amdgcn_exp2f(s0[r]);
             s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-            psum += s0[r] + s1[r];
         }
-        l_run += psum;                    // per-lane partial (this lane's 32 of the 64 keys)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {     // per-lane partials (this lane's 32 of the 64 keys)
+            l_run += (f32x2){s0[r], s0[r + 1]};
+            l_run1 += (f32x2){s1[r], s1[r + 1]};
+        }
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -279,7 +290,8 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     }
 
     // ---- normalise and store: o_db[r] = O[q = lr][d = db*32 + (r&3) + 8*(r>>2) + 4*hf] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_lane = (l_run[0] + l_run[1]) + (l_run1[0] + l_run1[1]);
+    const float l_tot = l_lane + __shfl_xor(l_lane, 32);
     const float inv = 1.0f / l_tot;
     if (qrow < p.Nq) {
         unsigned short* orow = Op + (int64_t)qrow * p.ldo;
