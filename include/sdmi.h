@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -106,9 +106,19 @@ typedef struct sdmi_gemm_args {
     int32_t algo;                       /* 0 = the library picks; 1 = the tiled kernel; 2 = the A-panel-stationary kernel
                                            (mode 0, K == 320, 16-bit output, N_w % 160 == 0 or GEGLU: every workgroup keeps
                                            its rows of A in LDS and streams all of W) - SDMI_ERR_BAD_ARG if it does not apply */
+    /* ln_gamma non-NULL: A is first layer-normalised over its K columns, y = (a - mean) * rstd * ln_gamma[k] + ln_beta[k]
+       (biased variance, fp32 statistics), rounded to the 16-bit operand type - the nn.LayerNorm in front of to_q/k/v, to_q
+       and the GEGLU projection (attention.py:512-514, 528-541) fused into the projection.  Only where the
+       A-panel-stationary kernel applies (sdmi_gemm_panel_applies() == 1: the whole row is resident in LDS);
+       SDMI_ERR_BAD_ARG otherwise - run sdmi_layernorm first in that case. */
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_eps;
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
+/* 1 if sdmi_gemm would run (algo 0) / can run (algo 2) this problem on the A-panel-stationary kernel, else 0. */
+int sdmi_gemm_panel_applies(const sdmi_gemm_args* args);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);

@@ -145,10 +145,12 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p.algo < 0 || p.algo > 2) return SDMI_ERR_BAD_ARG;
+    if (p.ln_gamma != nullptr && (p.ln_beta == nullptr || p.algo == 1 || !(p.ln_eps >= 0.f))) return SDMI_ERR_BAD_ARG;
+    if (p.ln_gamma == nullptr && p.ln_beta != nullptr) return SDMI_ERR_BAD_ARG;
     if (p.algo != 1) {       // short K, many rows: the A-panel-stationary kernel (sdmi_gemm_panel.h)
         const int st = sdmi_gemm_panel_launch(p, s);
         if (st != 0) return st < 0 ? st : SDMI_OK;
-        if (p.algo == 2) return SDMI_ERR_BAD_ARG;
+        if (p.algo == 2 || p.ln_gamma != nullptr) return SDMI_ERR_BAD_ARG;      // (the tiled kernel never holds a whole row)
     }
     // dynamic-LDS attribute of every instantiation, once per process (thread-safe; a refusal is reported, not ignored)
     static std::once_flag attr_once;

@@ -151,6 +151,59 @@ __global__ __launch_bounds__(WMW * 128, 2) void sdmi_gemm_panel_kernel(const sdm
     for (int s = 0; s < NSTW - 1; ++s)
         if (issued < steps) { issue_w(issued); ++issued; }
 
+    // ---- optional LayerNorm of the resident panel (the nn.LayerNorm in front of the projection, fused) ----
+    // Four threads per row, each owning the 16-byte chunks c with c % 4 == tid & 3 of every k-tile (2 * KT chunks,
+    // 16 * KT channels): exact two-pass statistics in fp32 as in layernorm_kernel, the normalised row rounded to the
+    // operand type and written back in place, so the MFMAs read what a separate LayerNorm launch would have stored.
+    if (p.ln_gamma != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the panel (and the first ring stages) have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        uint4* const ldsw = reinterpret_cast<uint4*>(smem);
+        const int row = tid >> 2, part = tid & 3;
+        float f[2 * KT][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 raw = ldsw[kt * A_KT_CHUNKS + row * 8 + ((part + 4 * h) ^ (row & 7))];
+                elem_unpack8<DT>(raw, f[2 * kt + h]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += f[2 * kt + h][j];
+            }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float inv_k = 1.0f / (float)(KT * BK);
+        const float mean = sum * inv_k;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2 * KT; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[c][j] - mean; q += d * d; }
+        q += __shfl_xor(q, 1);
+        q += __shfl_xor(q, 2);
+        const float rstd = rsqrtf(q * inv_k + p.ln_eps);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ch = kt * BK + (part + 4 * h) * 8;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + ch);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + ch + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + ch);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + ch + 4);
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] = (f[2 * kt + h][j] - mean) * rstd * g0[j] + b0[j];
+                    y[4 + j] = (f[2 * kt + h][4 + j] - mean) * rstd * g1[j] + b1[j];
+                }
+                ldsw[kt * A_KT_CHUNKS + row * 8 + ((part + 4 * h) ^ (row & 7))] = elem_pack8<DT>(y);
+            }
+        __syncthreads();      // the rewritten panel is visible to every wave (lgkmcnt + barrier)
+    }
+
     f32x4 acc[TN][MI];
 #pragma unroll
     for (int a = 0; a < TN; ++a)

@@ -20,21 +20,36 @@ const PanelVariant k320[2][3] = {SDMI_PANEL_SET(0), SDMI_PANEL_SET(1)};
 
 }  // namespace
 
-// 1 = launched, 0 = this problem is not one the panel kernel is built for, < 0 = sdmi_status
-int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s) {
+// the problems the panel kernel is built for
+static bool panel_applies(const sdmi_gemm_args& p) {
+    if (p.dtype != SDMI_DTYPE_BF16 && p.dtype != SDMI_DTYPE_F16) return false;
+    if (p.A == nullptr || p.W == nullptr || p.out == nullptr || p.algo == 1) return false;
     if (p.mode != 0 || p.batch > 1 || p.split_k > 1 || p.A2 != nullptr || p.emb != nullptr || p.bias_per_row || p.res_f32 ||
         p.out_kind != 0 || (p.k_valid != 0 && p.k_valid != p.K))
-        return 0;
-    if (p.K != 320 || p.M < 16384) return 0;      // fewer rows do not fill the chip with 64 / 128-row panels
+        return false;
+    if (p.K != 320 || p.M < 16384) return false;      // fewer rows do not fill the chip with 64 / 128-row panels
     const int64_t n_w = p.geglu ? 2 * p.N : p.N;
     const int bn = p.geglu ? 128 : 160;
-    if (n_w % bn != 0 || (p.N & 7) != 0) return 0;
-    if (((p.ld_out | p.ld_res) & 7) != 0 || (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0) return 0;
-    if (p.geglu && (p.res != nullptr || p.act != 0)) return 0;
-    int which;
-    if (p.geglu) which = 2;
-    else which = n_w >= 960 ? 1 : 0;
-    if ((p.M * p.lda + 8) * 2 >= (int64_t)1 << 32) { /* per-lane offsets are relative to the row tile: always small */ }
+    if (n_w % bn != 0 || (p.N & 7) != 0) return false;
+    if (((p.ld_out | p.ld_res | p.lda) & 7) != 0 || (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.A) & 15) != 0) return false;
+    if (p.geglu && (p.res != nullptr || p.act != 0)) return false;
+    if ((p.M + 127) / 128 * 2 > 0x7fffffffLL) return false;
+    return true;
+}
+
+extern "C" int sdmi_gemm_panel_applies(const sdmi_gemm_args* a) {
+    if (a == nullptr) return 0;
+    sdmi_gemm_args p = *a;
+    if (p.batch <= 0) p.batch = 1;
+    if (p.split_k <= 0) p.split_k = 1;
+    return panel_applies(p) ? 1 : 0;
+}
+
+// 1 = launched, 0 = this problem is not one the panel kernel is built for, < 0 = sdmi_status
+int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s) {
+    if (!panel_applies(p)) return 0;
+    const int64_t n_w = p.geglu ? 2 * p.N : p.N;
+    const int which = p.geglu ? 2 : (n_w >= 960 ? 1 : 0);
     static std::once_flag once;
     static int attr_status = SDMI_OK;
     std::call_once(once, [] {
@@ -47,7 +62,6 @@ int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s) {
     if (attr_status != SDMI_OK) return attr_status;
     const PanelVariant& v = k320[p.dtype == SDMI_DTYPE_F16 ? 1 : 0][which];
     const int64_t blocks = (p.M + v.bm - 1) / v.bm;
-    if (blocks > 0x7fffffffLL) return 0;
     hipLaunchKernelGGL(v.fn, dim3((unsigned)blocks), dim3(v.threads), v.lds, s, p);
     if (hipGetLastError() != hipSuccess) return SDMI_ERR_LAUNCH;
     return 1;

@@ -41,10 +41,11 @@ class GemmArgs(C.Structure):
         ("res_f32", C.c_int32),
         ("stages", C.c_int32),
         ("algo", C.c_int32),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
-ABI_VERSION = 7     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 8     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "sdmi_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "sdmi_gemm_tile_m": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32]),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "sdmi_gemm_panel_applies": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "sdmi_pack_tile_n": (_i32, [_i64, _i32]),
     "sdmi_pack_linear_k": (_i64, [_i64, _i32]),

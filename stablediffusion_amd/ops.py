@@ -303,11 +303,18 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     return None
 
 
+FUSE_LN = True      # tests / tools: False runs the LayerNorm of linear(..., ln=...) as its own launch everywhere
+
+
 def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True,
-           out_nchw_f32=None):
+           out_nchw_f32=None, ln=None):
     """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat).
+    ln = (gamma, beta[, eps]): out = epilogue(LayerNorm(x) @ W^T) - fused into the GEMM where the A-panel-stationary
+    kernel applies (sdmi_gemm_panel_applies), a sdmi_layernorm launch in front of it elsewhere.
     out_dtype: None = the operand type, or torch.float32.  fp32 mode (pw.split_cp): x (and x2, res) are fp32, the
     input is split into bf16 piece planes first and the output is fp32."""
+    if ln is not None and (pw.split_cp or x2 is not None or not FUSE_LN):
+        x, ln = layernorm(x, *ln), None
     if pw.split_cp:
         x = split3(x, pw.split_cp, x2)
         x2 = None
@@ -339,6 +346,17 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     else:
         out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
         keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
+    if ln is not None:
+        gamma, beta = ln[0], ln[1]
+        _require(gamma, torch.float32, "ln gamma")
+        _require(beta, torch.float32, "ln beta")
+        if gamma.numel() != k1 or beta.numel() != k1:
+            raise hip.SdmiError("linear: LayerNorm parameters do not match K")
+        if hip.lib().sdmi_gemm_panel_applies(C.byref(a)):
+            a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), ln[2] if len(ln) > 2 else 1e-5
+        else:
+            xn = layernorm(x, *ln)
+            a.A = xn.data_ptr()
     _run_gemm(a, "sdmi_gemm(linear)")
     del keep
     return out

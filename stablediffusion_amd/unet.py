@@ -389,17 +389,14 @@ class UNetModel(nn.Module):
         t = ops.linear(xn.reshape(b * n, c), e["pin"])
         for be in e["blocks"]:
             ci, heads = be["c"], be["heads"]
-            y = ops.layernorm(t, *be["ln1"])
-            qkv = ops.linear(y, be["qkv1"])
+            qkv = ops.linear(t, be["qkv1"], ln=be["ln1"])
             a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
             t = ops.linear(a, be["o1"], res=t)
-            y = ops.layernorm(t, *be["ln2"])
-            q2 = ops.linear(y, be["q2"])
+            q2 = ops.linear(t, be["q2"], ln=be["ln2"])
             ko = be["kv_off"]
             a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
             t = ops.linear(a, be["o2"], res=t)
-            y = ops.layernorm(t, *be["ln3"])
-            g = ops.linear(y, be["geglu"])
+            g = ops.linear(t, be["geglu"], ln=be["ln3"])
             t = ops.linear(g, be["ff2"], res=t)
         out = ops.linear(t, e["pout"], res=h.reshape(b * n, c))
         return out.reshape(b, hh, ww, c)

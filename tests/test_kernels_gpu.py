@@ -1,6 +1,7 @@
 """GPU parity of every HIP kernel behind the C ABI against a plain fp32 PyTorch statement of the same op
 on the same bf16-rounded inputs (floating-point kernels: tolerance written per test; the bf16 output
 rounding alone is 2^-9 relative)."""
+import ctypes as C
 import math
 
 import pytest
@@ -412,6 +413,56 @@ def test_panel_gemm_k320_geglu(dev, dt, m, inner):
     ref = a_ * F.gelu(g_)
     tol = 8e-3 if dt == BF16 else 1.5e-3
     assert rel_err(outs[2], ref) < tol and rel_err(outs[1], ref) < tol
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16])
+@pytest.mark.parametrize("kind,m,n", [("lin", 16384, 320), ("lin", 16500, 960), ("geglu", 16384, 1280)])
+def test_panel_gemm_fused_layernorm(dev, dt, kind, m, n):
+    """linear(..., ln=(gamma, beta)) on the panel kernel (the LayerNorm of attention.py:512-514 applied to the resident
+    rows in LDS) against sdmi_layernorm + the same GEMM, and against torch on the rounded operands."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    x = (rnd((m, 320), dev, 41) * 1.7 + 0.4).to(dt)
+    gamma, beta = 1.0 + 0.2 * rnd((320,), dev, 42), 0.3 * rnd((320,), dev, 43)
+    if kind == "geglu":
+        w, b = rnd((2 * n, 320), dev, 44, 0.06), rnd((2 * n,), dev, 45)
+        pw = ops.pack_geglu(w, b, dtype=dt)
+    else:
+        w, b = rnd((n, 320), dev, 44, 0.06), rnd((n,), dev, 45)
+        pw = ops.pack_linear(w, b, dtype=dt)
+    fused = ops.linear(x, pw, ln=(gamma, beta))
+    ops.FUSE_LN = False
+    try:
+        split = ops.linear(x, pw, ln=(gamma, beta))
+    finally:
+        ops.FUSE_LN = True
+    y = qd(F.layer_norm(x.float(), (320,), gamma, beta, 1e-5))
+    ref = F.linear(y, qd(w), b)
+    if kind == "geglu":
+        a_, g_ = ref.chunk(2, dim=-1)
+        ref = a_ * F.gelu(g_)
+    tol = 8e-3 if dt == BF16 else 1.5e-3
+    assert rel_err(fused, ref) < tol and rel_err(split, ref) < tol
+    assert rel_err(fused, split.float()) < (4e-3 if dt == BF16 else 6e-4)      # same arithmetic up to the order of the row sums
+
+
+def test_fused_layernorm_falls_back_and_refuses(dev):
+    """Where the panel kernel does not apply, ops.linear runs sdmi_layernorm itself; the C entry point refuses."""
+    ops = _ops()
+    x = rnd((4096, 640), dev, 46).to(BF16)
+    gamma, beta = 1.0 + 0.2 * rnd((640,), dev, 47), 0.3 * rnd((640,), dev, 48)
+    w = rnd((640, 640), dev, 49, 0.05)
+    pw = ops.pack_linear(w)
+    out = ops.linear(x, pw, ln=(gamma, beta))
+    ref = F.linear(F.layer_norm(x.float(), (640,), gamma, beta, 1e-5).to(BF16).float(), w.to(BF16).float())
+    assert rel_err(out, ref) < 8e-3
+    a = ops.hip.GemmArgs()
+    o = torch.empty(4096, 640, dtype=BF16, device=dev)
+    a.mode, a.A, a.lda, a.M, a.W, a.N, a.K = 0, x.data_ptr(), 640, 4096, pw.w.data_ptr(), 640, 640
+    a.out, a.ld_out, a.dtype, a.tile_n, a.alpha, a.batch, a.split_k = o.data_ptr(), 640, 0, pw.tile_n, 1.0, 1, 1
+    a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), 1e-5
+    assert ops.hip.lib().sdmi_gemm_panel_applies(C.byref(a)) == 0
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # SDMI_ERR_BAD_ARG
 
 
 def test_panel_gemm_refuses_what_it_is_not_built_for(dev):
