@@ -200,7 +200,7 @@ def _plan_gemm(m, n_w, k, tile_n=_BN):
         # epilogue of one block overlaps the main loop of the other (bench_gemm: +5..15% over the 256-row tile)
         return (128, 1, 2)
     best, best_cost = (128, 1, 3), None
-    for tile_m, step_us in ((256, 1.2 * tile_n / 160), (128, 0.67 * tile_n / 160)):
+    for tile_m, step_us in ((256, 1.12 * tile_n / 160), (128, 0.67 * tile_n / 160)):
         tiles = math.ceil(m / tile_m) * math.ceil(n_w / tile_n)
         for s in range(1, 17):
             if s > 1 and nk // s < 2:
@@ -210,7 +210,7 @@ def _plan_gemm(m, n_w, k, tile_n=_BN):
             if blocks < _CUS:
                 cost *= 0.8 + 0.2 * blocks / _CUS       # a partly idle chip clocks higher and contends less
             if s > 1:
-                cost += (2 * s + 0.5) * m * n_w * 4 / 8.0e6 + 7.0   # slab write+read (mostly L2/MALL) + the extra launch
+                cost += (2 * s + 0.5) * m * n_w * 4 / 12.0e6 + 6.0   # slab write+read (mostly L2/MALL) + the extra launch
             if best_cost is None or cost < best_cost * 0.97:
                 best, best_cost = (tile_m, s, 3), cost
     return best

@@ -26,6 +26,11 @@ SHAPES += [("linnr", (65536, 960, 320)), ("linnr", (65536, 320, 320)), ("linnr",
            ("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
 auto_split = ops._auto_split_k
 configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
+SHAPES += [("conv", (16, 16, 16, 640, 640)), ("lin", (1024, 1280, 1280)), ("conv", (16, 16, 16, 1920, 1280))]
+if os.environ.get("CONFIGS"):      # CONFIGS=256:8,128:4  -> (tile_m, split) pairs; SHAPE=<substring of the shape tuple> filters
+    configs = [(None, c.split(":")[1], c.split(":")[0]) for c in os.environ["CONFIGS"].split(",")]
+if os.environ.get("SHAPE"):
+    SHAPES = [sh for sh in SHAPES if os.environ["SHAPE"] in str(sh[1])]
 if os.environ.get("SWEEP"):
     configs = [(None, s, tm) for tm in ("128", "129", "256") for s in (None, "1", "2", "4")]
 for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in configs]:
