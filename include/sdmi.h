@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -288,7 +288,13 @@ int sdmi_f32_layernorm(const float* x, const float* gamma, const float* beta, fl
 int sdmi_f32_attention_d64(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t heads,
                            int32_t Nq, int32_t Nk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
                            void* stream);
-int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, void* stream);
+int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, float scale, void* stream);   /* out = scale * x */
+/* fp32 counterpart of sdmi_attention_vae (AttnBlock, ldm/modules/diffusion/model.py:496-528): same arguments and modes
+ * (0 standard, 1 the reference's contraction over the query index), same workspace (sdmi_attention_vae_workspace_bytes),
+ * D in {64, 128, 256, 512}, leading dimensions multiples of 4, any N.  Two passes, no [B, N, N] tensor. */
+int sdmi_f32_attention_vae(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t N, int32_t D,
+                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int32_t mode, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 int sdmi_f32_timestep_embedding(const int64_t* t, float* out, int32_t nb, int32_t dim, float max_period, void* stream);
 
 /* Text conditioning stage (cond_stage_config, configs/stable-diffusion/v2-inference.yaml:63-67, called from

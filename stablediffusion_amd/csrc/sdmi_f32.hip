@@ -147,6 +147,100 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
     }
 }
 
+// Single-head attention of the VAE's AttnBlock (model.py:496-528) in fp32 - the counterpart of sdmi_attention_vae,
+// same two passes (row statistics over all keys, then the weighted sum with the logits recomputed; no [B, N, N]
+// tensor), plain FMA on the VALU.  16 output rows per 256-thread block, 16 lanes per row, each lane owning D / 16
+// channels as interleaved float4s (the 16 lanes of a row read 256 contiguous bytes); Y (and V) rows are staged through
+// LDS TK at a time and read by broadcast across the four rows of a wave.
+//   MODE 0: statistics (m_i, 1 / l_i) of the rows of X against all Y.
+//   MODE 1: O[r, :] = sum_c w(r, c) V[c, :], w = exp(s - m_r) / l_r           (standard: X = Q, Y = K)
+//   MODE 2: ... w = exp(s - m_c) / l_c, the statistics of the contraction index (reference: X = K, Y = Q, defect B7)
+template <int DC, int MODE>
+__global__ __launch_bounds__(256) void attn_vae_f32_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ v, float* __restrict__ out,
+                                                           float* __restrict__ stats, int N, int64_t ldx, int64_t ldy,
+                                                           int64_t ldv, int64_t ldo, float scale) {
+    constexpr int D = DC * 64, TK = MODE == 0 ? 16 : 8;
+    __shared__ __attribute__((aligned(16))) float Ys[TK][D];
+    __shared__ __attribute__((aligned(16))) float Vs[MODE == 0 ? 1 : TK][MODE == 0 ? 4 : D];
+    __shared__ float Cs[TK][2];
+    const int b = blockIdx.y, t = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int row = blockIdx.x * 16 + rl;
+    const int rowc = row < N ? row : N - 1;
+    const float* xp = x + ((int64_t)b * N + rowc) * ldx;
+    const float* yb = y + (int64_t)b * N * ldy;
+    const float* vb = v + (int64_t)b * N * ldv;
+    float* sb = stats + (int64_t)b * N * 2;
+    f32x4 xr[DC], o[DC];
+#pragma unroll
+    for (int u = 0; u < DC; ++u) {
+        xr[u] = *reinterpret_cast<const f32x4*>(xp + u * 64 + t * 4);
+        o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float m = -INFINITY, l = 0.f, il = 0.f;
+    if (MODE == 1) { m = sb[2 * rowc]; il = sb[2 * rowc + 1]; }
+    for (int c0 = 0; c0 < N; c0 += TK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < TK * (D / 4); e += 256) {
+            const int r = e / (D / 4), d4 = e - r * (D / 4);
+            const int c = c0 + r < N ? c0 + r : N - 1;
+            *reinterpret_cast<f32x4*>(&Ys[r][d4 * 4]) = *reinterpret_cast<const f32x4*>(yb + (int64_t)c * ldy + d4 * 4);
+            if (MODE != 0)
+                *reinterpret_cast<f32x4*>(&Vs[r][d4 * 4]) = *reinterpret_cast<const f32x4*>(vb + (int64_t)c * ldv + d4 * 4);
+        }
+        if (MODE == 2 && threadIdx.x < TK) {
+            const int c = c0 + threadIdx.x < N ? c0 + threadIdx.x : N - 1;
+            Cs[threadIdx.x][0] = sb[2 * c];
+            Cs[threadIdx.x][1] = sb[2 * c + 1];
+        }
+        __syncthreads();
+        const int kn = N - c0 < TK ? N - c0 : TK;
+        for (int j = 0; j < kn; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < DC; ++u) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(&Ys[j][u * 64 + t * 4]);
+                s = fmaf(xr[u][0], yv[0], s); s = fmaf(xr[u][1], yv[1], s);
+                s = fmaf(xr[u][2], yv[2], s); s = fmaf(xr[u][3], yv[3], s);
+            }
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s *= scale;
+            if (MODE == 0) {
+                const float mn = fmaxf(m, s);
+                l = l * expf(m - mn) + expf(s - mn);
+                m = mn;
+            } else {
+                const float w = MODE == 1 ? expf(s - m) * il : expf(s - Cs[j][0]) * Cs[j][1];
+#pragma unroll
+                for (int u = 0; u < DC; ++u) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[j][u * 64 + t * 4]);
+                    o[u][0] = fmaf(w, vv[0], o[u][0]); o[u][1] = fmaf(w, vv[1], o[u][1]);
+                    o[u][2] = fmaf(w, vv[2], o[u][2]); o[u][3] = fmaf(w, vv[3], o[u][3]);
+                }
+            }
+        }
+    }
+    if (row >= N) return;
+    if (MODE == 0) {
+        if (t == 0) { sb[2 * row] = m; sb[2 * row + 1] = 1.0f / l; }
+    } else {
+        float* op = out + ((int64_t)b * N + row) * ldo;
+#pragma unroll
+        for (int u = 0; u < DC; ++u) *reinterpret_cast<f32x4*>(op + u * 64 + t * 4) = o[u];
+    }
+}
+
+template <int DC>
+void launch_attn_vae_f32(const float* q, const float* k, const float* v, float* out, float* stats, int nb, int N, int64_t ldq,
+                         int64_t ldk, int64_t ldv, int64_t ldo, float scale, int mode, hipStream_t s) {
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)nb);
+    hipLaunchKernelGGL((attn_vae_f32_kernel<DC, 0>), grid, dim3(256), 0, s, q, k, v, out, stats, N, ldq, ldk, ldv, ldo, scale);
+    if (mode == 0)
+        hipLaunchKernelGGL((attn_vae_f32_kernel<DC, 1>), grid, dim3(256), 0, s, q, k, v, out, stats, N, ldq, ldk, ldv, ldo, scale);
+    else
+        hipLaunchKernelGGL((attn_vae_f32_kernel<DC, 2>), grid, dim3(256), 0, s, k, q, v, out, stats, N, ldk, ldq, ldv, ldo, scale);
+}
+
 // out[r, :] = table[ids[r], :] + pos[r % T, :]  (token + positional embedding of a text transformer).  An id outside
 // [0, vocab) is clamped: the host wrapper has already rejected it, this only keeps the access in bounds.
 __global__ __launch_bounds__(256) void embed_tokens_f32_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
@@ -166,14 +260,14 @@ __global__ __launch_bounds__(256) void embed_tokens_f32_kernel(const int64_t* __
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int nb,
-                                                               int C, int64_t hw) {
+                                                               int C, int64_t hw, float scale) {
     const int64_t total = (int64_t)nb * C * hw;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = idx % hw;
         const int64_t r = idx / hw;
         const int c = (int)(r % C);
         const int64_t b = r / C;
-        out[(b * hw + pix) * C + c] = x[idx];
+        out[(b * hw + pix) * C + c] = x[idx] * scale;
     }
 }
 
@@ -259,6 +353,28 @@ extern "C" int sdmi_f32_attention_d64_causal(const float* q, const float* k, con
     return launch_attn_f32(q, k, v, out, nb, heads, N, N, ldq, ldk, ldv, ldo, scale, 1, stream);
 }
 
+extern "C" int sdmi_f32_attention_vae(const float* q, const float* k, const float* v, float* out, int32_t nb, int32_t N,
+                                      int32_t D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                                      int32_t mode, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
+    if (nb <= 0 || nb > 65535 || N <= 0 || (mode != 0 && mode != 1)) return SDMI_ERR_BAD_ARG;
+    if (D != 64 && D != 128 && D != 256 && D != 512) return SDMI_ERR_BAD_ARG;
+    if (ldq < D || ldk < D || ldv < D || ldo < D) return SDMI_ERR_BAD_ARG;
+    if (((ldq | ldk | ldv | ldo) & 3) != 0 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) != 0)
+        return SDMI_ERR_ALIGNMENT;
+    if (workspace == nullptr || workspace_bytes < (int64_t)nb * N * 2 * (int64_t)sizeof(float)) return SDMI_ERR_WORKSPACE;
+    float* st = reinterpret_cast<float*>(workspace);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (D) {
+        case 64:  launch_attn_vae_f32<1>(q, k, v, out, st, nb, N, ldq, ldk, ldv, ldo, scale, mode, s); break;
+        case 128: launch_attn_vae_f32<2>(q, k, v, out, st, nb, N, ldq, ldk, ldv, ldo, scale, mode, s); break;
+        case 256: launch_attn_vae_f32<4>(q, k, v, out, st, nb, N, ldq, ldk, ldv, ldo, scale, mode, s); break;
+        default:  launch_attn_vae_f32<8>(q, k, v, out, st, nb, N, ldq, ldk, ldv, ldo, scale, mode, s); break;
+    }
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
 extern "C" int sdmi_f32_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* out, int64_t rows,
                                      int32_t T, int32_t C, int32_t vocab, void* stream) {
     if (ids == nullptr || table == nullptr || pos == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
@@ -269,10 +385,11 @@ extern "C" int sdmi_f32_embed_tokens(const int64_t* ids, const float* table, con
     return SDMI_OK;
 }
 
-extern "C" int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, void* stream) {
+extern "C" int sdmi_f32_nchw_to_nhwc(const float* x, float* out, int32_t nb, int32_t C, int64_t hw, float scale,
+                                     void* stream) {
     if (x == nullptr || out == nullptr || nb <= 0 || C <= 0 || hw <= 0) return SDMI_ERR_BAD_ARG;
     hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(blocks_for((int64_t)nb * C * hw)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, out, nb, C, hw);
+                       reinterpret_cast<hipStream_t>(stream), x, out, nb, C, hw, scale);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

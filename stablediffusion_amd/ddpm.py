@@ -125,7 +125,7 @@ class LatentDiffusion(nn.Module):
             p.requires_grad = False
         # one precision policy for the whole path: the VAE follows the UNet's operand type
         cd = getattr(self.model.diffusion_model, "compute_dtype", None)
-        if cd in (torch.bfloat16, torch.float16) and hasattr(model, "set_compute_dtype"):
+        if cd in (torch.bfloat16, torch.float16, torch.float32) and hasattr(model, "set_compute_dtype"):
             model.set_compute_dtype(cd)
 
     def instantiate_cond_stage(self, config):

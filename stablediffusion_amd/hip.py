@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 8     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 9     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -59,7 +59,8 @@ SIGNATURES = {
     "sdmi_f32_groupnorm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp]),
     "sdmi_f32_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "sdmi_f32_attention_d64": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
-    "sdmi_f32_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
+    "sdmi_f32_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _f32, _vp]),
+    "sdmi_f32_attention_vae": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _i32, _vp, _i64, _vp]),
     "sdmi_f32_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "sdmi_f32_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "sdmi_f32_attention_d64_causal": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),

@@ -510,7 +510,7 @@ def attention_d64(q, k, v, heads, nb, nq, nk, scale, causal=False):
 
 
 def attention_vae(q, k, v, nb, n, scale, mode):
-    """Single-head attention over [nb*n, D] 16-bit matrices (row strides from the tensors, inner stride 1):
+    """Single-head attention over [nb*n, D] 16-bit (or, in fp32 mode, fp32) matrices (row strides from the tensors, inner stride 1):
     mode "standard" = softmax(QK^T) V, "reference" = the reference's contraction over the query index
     (model.py:519-523).  Two launches, no [nb, n, n] tensor (sdmi_attention_vae)."""
     d = q.shape[-1]
@@ -519,10 +519,15 @@ def attention_vae(q, k, v, nb, n, scale, mode):
             raise hip.SdmiError(f"attention_vae: bad {name}")
     if mode not in ("standard", "reference"):
         raise ValueError(f"vae_attn must be 'reference' or 'standard', got {mode!r}")
-    dt = _dt(q.dtype)
     out = torch.empty(nb * n, d, dtype=q.dtype, device=q.device)
     nbytes = hip.lib().sdmi_attention_vae_workspace_bytes(nb, n)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    if q.dtype == torch.float32:          # fp32 mode of the path
+        hip.check(hip.lib().sdmi_f32_attention_vae(_p(q), _p(k), _p(v), _p(out), nb, n, d, q.stride(0), k.stride(0),
+                                                   v.stride(0), out.stride(0), scale, 1 if mode == "reference" else 0,
+                                                   _p(ws), nbytes, _stream()), "sdmi_f32_attention_vae")
+        return out
+    dt = _dt(q.dtype)
     hip.check(hip.lib().sdmi_attention_vae(_p(q), _p(k), _p(v), _p(out), nb, n, d, q.stride(0), k.stride(0), v.stride(0),
                                            out.stride(0), scale, 1 if mode == "reference" else 0, dt, _p(ws), nbytes,
                                            _stream()), "sdmi_attention_vae")
@@ -575,10 +580,8 @@ def nchw_to_nhwc(x, cpad=None, scale=1.0, dtype=BF16):
     _require(x, torch.float32, "x")
     b, c, h, w = x.shape
     if dtype == torch.float32:
-        if scale != 1.0:
-            raise hip.SdmiError("nchw_to_nhwc: scale is not supported in fp32 mode")
         out = torch.empty(b, h, w, c, dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().sdmi_f32_nchw_to_nhwc(_p(x), _p(out), b, c, h * w, _stream()), "sdmi_f32_nchw_to_nhwc")
+        hip.check(hip.lib().sdmi_f32_nchw_to_nhwc(_p(x), _p(out), b, c, h * w, scale, _stream()), "sdmi_f32_nchw_to_nhwc")
         return out
     cpad = cpad or _round_up(c, 8)
     out = torch.empty(b, h, w, cpad, dtype=dtype, device=x.device)

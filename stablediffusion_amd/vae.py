@@ -78,9 +78,10 @@ class _VaeNet(nn.Module):
         self._pack = None
 
     def set_compute_dtype(self, dtype):
-        """bf16 or fp16 storage / MFMA operand type (LatentDiffusion aligns it with the UNet's policy)."""
-        if dtype not in ops.HALF_TYPES:
-            raise NotImplementedError("HIP VAE: compute dtype must be torch.bfloat16 or torch.float16")
+        """bf16 or fp16 storage / MFMA operand type, or torch.float32 = the fp32 mode of the path (fp32 activations,
+        contractions on exact three-way bf16 splits; LatentDiffusion aligns it with the UNet's policy)."""
+        if dtype not in ops.HALF_TYPES and dtype != torch.float32:
+            raise NotImplementedError("HIP VAE: compute dtype must be torch.bfloat16, torch.float16 or torch.float32")
         if dtype != self.compute_dtype:
             self.compute_dtype = dtype
             self._pack = None
@@ -131,7 +132,7 @@ class _VaeNet(nn.Module):
         n = hh * ww
         if self.vae_attn not in ("reference", "standard"):
             raise ValueError(f"vae_attn must be 'reference' or 'standard', got {self.vae_attn!r}")
-        if c not in (64, 128, 256, 512) or n % 2:
+        if c not in (64, 128, 256, 512) or (n % 2 and self.compute_dtype != torch.float32):
             raise NotImplementedError("VAE attention is built for 64 / 128 / 256 / 512 channels and an even token count")
         hn = ops.groupnorm(h, e["gn"][0], e["gn"][1], 1e-6, False).reshape(b * n, c)
         qkv = ops.linear(hn, e["qkv"])
@@ -273,12 +274,16 @@ class Decoder(_VaeNet):
         self._pack = None
 
     @torch.no_grad()
-    def forward(self, z, scale=1.0):
-        """z: fp32 NCHW latent [B, z_channels, h, w] (or an already-NHWC bf16 tensor from decode()) ->
-        fp32 NCHW image [B, out_channels, 8h, 8w] (model.py:371-411)."""
+    def forward(self, z, scale=1.0, nhwc=None):
+        """z: fp32 NCHW latent [B, z_channels, h, w] (or, nhwc=True, the channels-last activation decode() hands over:
+        16-bit, or fp32 in fp32 mode) -> fp32 NCHW image [B, out_channels, 8h, 8w] (model.py:371-411)."""
         pk = self._pack or self._build_pack()
-        h = z if z.dtype in ops.HALF_TYPES else ops.nchw_to_nhwc(z.float().contiguous(), scale=scale,
-                                                                  dtype=self.compute_dtype)
+        if nhwc is None:
+            nhwc = z.dtype in ops.HALF_TYPES
+        if nhwc:
+            h = z
+        else:
+            h = ops.nchw_to_nhwc(z.float().contiguous(), scale=scale, dtype=self.compute_dtype)
         h = ops.conv3x3(h, pk["conv_in"])
         h = self._resnet(pk, self.mid.block_1, h)
         h = self._attn(pk, self.mid.attn_1, h)
@@ -358,6 +363,12 @@ class AutoencoderKL(nn.Module):
     def decode(self, z, scale=1.0):
         """post_quant_conv (1x1, autoencoder.py:54) then Decoder.  `scale` multiplies z first
         (decode_first_stage passes 1/scale_factor so the division is fused into the layout kernel)."""
+        if self.decoder.compute_dtype == torch.float32:      # fp32 mode: no channel padding (split3 pads per plane)
+            if self._pq is None:
+                w = self.post_quant_conv.weight
+                self._pq = ops.pack_linear(w.reshape(w.shape[0], w.shape[1]), self.post_quant_conv.bias, dtype=torch.float32)
+            h = ops.nchw_to_nhwc(z.float().contiguous(), scale=scale, dtype=torch.float32)        # [B, h, w, embed_dim]
+            return self.decoder(ops.linear(h, self._pq), nhwc=True)
         if self._pq is None:
             w = self.post_quant_conv.weight.detach().float()
             zc, ed = w.shape[0], w.shape[1]
@@ -370,7 +381,7 @@ class AutoencoderKL(nn.Module):
         h = ops.nchw_to_nhwc(z.float().contiguous(), cpad=self._pq.k, scale=scale,
                              dtype=self.decoder.compute_dtype)                        # [B, h, w, 64], zero padded
         h = ops.linear(h, self._pq)                                                    # [B, h, w, 8]
-        return self.decoder(h)
+        return self.decoder(h, nhwc=True)
 
     def forward(self, z):
         return self.decode(z)

@@ -530,6 +530,23 @@ def test_attention_vae(dev, dt, nb, n, d, mode):
     assert rel_err(out.reshape(nb, n, d), ref) < (1.2e-2 if dt == BF16 else 2e-3)
 
 
+@pytest.mark.parametrize("mode", ["standard", "reference"])
+@pytest.mark.parametrize("nb,n,d", [(2, 100, 64), (1, 333, 128), (2, 256, 512)])
+def test_attention_vae_fp32_mode(dev, nb, n, d, mode):
+    """sdmi_f32_attention_vae (the fp32 mode's AttnBlock) against the formulas of model.py:514-525 in float64: ragged
+    row blocks and contraction tiles, an odd token count, q | k | v as column slices of one buffer."""
+    ops = _ops()
+    qkv = rnd((nb * n, 3 * d), dev, 23) * 1.5
+    qkv[n // 3, d:2 * d] *= 3.0
+    out = ops.attention_vae(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], nb, n, d ** -0.5, mode)
+    f = qkv.double().reshape(nb, n, 3 * d)
+    qq, kk, vv = f[..., :d], f[..., d:2 * d], f[..., 2 * d:]
+    w = (torch.einsum("bid,bjd->bij", qq, kk) * d ** -0.5).softmax(-1)
+    ref = torch.einsum("bij,bjd->bid", w, vv) if mode == "standard" else torch.einsum("bij,bid->bjd", w, vv)
+    assert out.dtype == torch.float32 and out.shape == (nb * n, d)
+    assert rel_err(out.reshape(nb, n, d).double(), ref) < 2e-6
+
+
 def test_attention_vae_argument_checks(dev):
     import ctypes as C
     from stablediffusion_amd import hip

@@ -95,6 +95,41 @@ def test_tiny_decoder_vs_oracle(dev, mode, dt):
         assert rel_err(img, gold) < TOL[dt]
 
 
+@pytest.mark.parametrize("mode", ["reference", "standard"])
+def test_tiny_decoder_fp32_mode(dev, mode):
+    """fp32 mode of the VAE decoder (compute_dtype = torch.float32: fp32 activations, contractions on exact three-way
+    bf16 splits, sdmi_f32_attention_vae) against the fp32 oracle and the reference's golden at the fp32-mode gate."""
+    from oracle import model as OM
+    from stablediffusion_amd.vae import Decoder
+    m, sd = build(Decoder, synth.TINY_DDCONFIG, "decoder.", dev, vae_attn=mode, compute_dtype=torch.float32)
+    zz = synth.synth_input("tiny_z", (2, 4, 16, 16))
+    img = m(zz.to(dev))
+    ref = OM.decoder_forward({"decoder." + k: v for k, v in sd.items()}, synth.TINY_DDCONFIG, zz, p="decoder.",
+                             vae_attn=mode)
+    print(f"[parity] tiny decoder fp32 mode ({mode}) vs oracle: rel_err {rel_err(img, ref):.3e}")
+    assert img.dtype == torch.float32 and img.shape == ref.shape
+    assert rel_err(img, ref) < 1e-5
+    if mode == "reference":
+        gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny_decoder.npz"))["out"])
+        assert rel_err(img, gold) < 1e-5
+
+
+def test_sd2_decode_fp32_mode(dev):
+    """AutoencoderKL.decode (post_quant_conv + the SD2 decoder, 512-channel mid attention) in fp32 mode on a 16x24
+    latent, the 1/scale_factor fused into the layout kernel: against the fp32 oracle at the fp32-mode gate."""
+    from oracle import model as OM
+    from stablediffusion_amd.vae import AutoencoderKL
+    vae, vsd = build(AutoencoderKL, dict(ddconfig=synth.SD2_DDCONFIG, embed_dim=4), "vae.", dev)
+    vae.set_compute_dtype(torch.float32)
+    z = synth.synth_input("f32_z", (1, 4, 16, 24))
+    img = vae.decode(z.to(dev), 1 / 0.18215)
+    with torch.no_grad():
+        ref = OM.vae_decode(vsd, synth.SD2_DDCONFIG, z / 0.18215)
+    e = rel_err(img, ref)
+    print(f"[parity] sd2 decoder 16x24 latent, fp32 mode: rel_err vs fp32 oracle {e:.3e}")
+    assert img.shape == (1, 3, 128, 192) and e < 1e-5
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_sd2_unet_h32_vs_reference_golden(dev, dt):
     """Full v2-inference.yaml UNet (866 M parameters), 32x32 latent: against values the reference's own
