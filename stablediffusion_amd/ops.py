@@ -24,6 +24,24 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SCRATCH = {}     # (device index, stream handle) -> grow-only byte buffer
+
+
+def _scratch(nbytes, device):
+    """Workspace for one launch sequence (split-K slabs, GroupNorm slab partials, attention row statistics): a static,
+    grow-only arena per (device, stream) instead of an allocation per launch - every user writes its workspace before it
+    reads it, and launches on one stream are ordered, so consecutive users may share the bytes.  Under stream capture
+    the caching allocator's graph pool owns the lifetime, so a plain allocation is made there."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -294,7 +312,7 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.stages = 2 if FORCE_TILE_M & 1 else 3         # 129 = 128 rows, two stages
     if sk > 1:
         nbytes = hip.lib().sdmi_gemm_workspace_bytes(m, n_w, sk)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+        ws = _scratch(nbytes, out.device)
         a.workspace = ws.data_ptr()
         a.workspace_bytes = nbytes
         a.split_k = sk
@@ -454,7 +472,7 @@ def groupnorm(x1, gamma, beta, eps, silu, x2=None):
     hw = x1.numel() // (b * c1)
     out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=x1.dtype, device=x1.device)
     nbytes = hip.lib().sdmi_groupnorm_workspace_bytes(b, hw)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x1.device)
+    ws = _scratch(nbytes, x1.device)
     _traced("groupnorm", 2 * out.numel() * out.element_size(), (b, hw, c1 + c2),
             lambda: hip.check(hip.lib().sdmi_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b, hw, eps,
                                                        1 if silu else 0, dt, _p(ws), nbytes, _stream()), "sdmi_groupnorm"))
@@ -521,7 +539,7 @@ def attention_vae(q, k, v, nb, n, scale, mode):
         raise ValueError(f"vae_attn must be 'reference' or 'standard', got {mode!r}")
     out = torch.empty(nb * n, d, dtype=q.dtype, device=q.device)
     nbytes = hip.lib().sdmi_attention_vae_workspace_bytes(nb, n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    ws = _scratch(nbytes, q.device)
     if q.dtype == torch.float32:          # fp32 mode of the path
         hip.check(hip.lib().sdmi_f32_attention_vae(_p(q), _p(k), _p(v), _p(out), nb, n, d, q.stride(0), k.stride(0),
                                                    v.stride(0), out.stride(0), scale, 1 if mode == "reference" else 0,
@@ -566,7 +584,7 @@ def softmax_cols(st, out_dtype=BF16):
     z, rows, cols = st.shape
     out = torch.empty(st.shape, dtype=out_dtype, device=st.device)
     nbytes = hip.lib().sdmi_softmax_cols_scratch_bytes(z, cols)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=st.device)
+    ws = _scratch(nbytes, st.device)
     hip.check(hip.lib().sdmi_softmax_cols(_p(st), _p(out), _p(ws), z, rows, cols, _dt(out_dtype), _stream()),
               "sdmi_softmax_cols")
     return out
