@@ -69,6 +69,7 @@ SDMI_GEMM_UNIT_DECL(m0_bf16) SDMI_GEMM_UNIT_DECL(m0_f16) SDMI_GEMM_UNIT_DECL(m1_
 #undef SDMI_GEMM_UNIT_DECL
 
 int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s);      // sdmi_gemm_panel.hip
+int sdmi_conv_narrow_launch(const sdmi_gemm_args& p, hipStream_t s);     // sdmi_conv_narrow.hip
 
 // Row tile the launcher picks: 256 rows once that still gives every CU a block, else 128 rows.
 static int pick_tile_m(int64_t M, int64_t N_w, int tile_n, int64_t problems) {
@@ -147,6 +148,10 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (p.algo < 0 || p.algo > 2) return SDMI_ERR_BAD_ARG;
     if (p.ln_gamma != nullptr && (p.ln_beta == nullptr || p.algo == 1 || !(p.ln_eps >= 0.f))) return SDMI_ERR_BAD_ARG;
     if (p.ln_gamma == nullptr && p.ln_beta != nullptr) return SDMI_ERR_BAD_ARG;
+    if (p.algo == 0 && p.mode == 1 && p.ln_gamma == nullptr) {      // conv3x3 with <= 16 output channels: the byte-bound narrow kernel
+        const int st = sdmi_conv_narrow_launch(p, s);
+        if (st != 0) return st < 0 ? st : SDMI_OK;
+    }
     if (p.algo != 1) {       // short K, many rows: the A-panel-stationary kernel (sdmi_gemm_panel.h)
         const int st = sdmi_gemm_panel_launch(p, s);
         if (st != 0) return st < 0 ? st : SDMI_OK;

@@ -245,6 +245,33 @@ def test_conv3x3_edges(dev):
     assert rel_err(out.permute(0, 3, 1, 2), ref) < 6e-3
 
 
+@pytest.mark.parametrize("dt", [BF16, torch.float16])
+@pytest.mark.parametrize("b,h,w,cin,cout,kind", [(2, 20, 24, 128, 3, "nchw"), (1, 33, 17, 320, 4, "nchw"),
+                                                 (3, 9, 11, 64, 8, "nhwc"), (2, 16, 16, 96, 16, "nhwc"), (1, 5, 3, 32, 1, "nchw")])
+def test_conv3x3_narrow(dev, dt, b, h, w, cin, cout, kind):
+    """conv3x3 with <= 16 output channels (UNet `out` 320 -> 4, decoder conv_out 128 -> 3) runs the byte-bound narrow
+    kernel (sdmi_conv_narrow.hip): against F.conv2d on the rounded operands and against the tiled kernel (algo = 1) -
+    templated (Cin 128 / 320) and run-time channel loops, odd Cin / 32, row counts that are not multiples of 16, image
+    borders, fp32 NCHW and 16-bit NHWC outputs."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    x = rnd((b, cin, h, w), dev, 51)
+    wt, bias = rnd((cout, cin, 3, 3), dev, 52, (9 * cin) ** -0.5), rnd((cout,), dev, 53)
+    x_nhwc = qd(x).permute(0, 2, 3, 1).contiguous().to(dt)
+    pw = ops.pack_conv3x3(wt, bias, dtype=dt)
+    ref = F.conv2d(qd(x), qd(wt), bias, padding=1)
+    outs = {}
+    for algo in (0, 1):
+        ops.FORCE_ALGO = algo
+        try:
+            o = ops.conv3x3(x_nhwc, pw, out_nchw_f32=(kind == "nchw"))
+        finally:
+            ops.FORCE_ALGO = 0
+        outs[algo] = o if kind == "nchw" else o.permute(0, 3, 1, 2).float()
+    tol = 1e-4 if kind == "nchw" else (6e-3 if dt == BF16 else 1e-3)
+    assert outs[0].shape == ref.shape and rel_err(outs[0], ref) < tol and rel_err(outs[1], ref) < tol
+
+
 def test_batched_gemm(dev):
     ops = _ops()
     z, m, n, k = 3, 256, 256, 512

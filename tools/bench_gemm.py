@@ -26,7 +26,7 @@ SHAPES += [("linnr", (65536, 960, 320)), ("linnr", (65536, 320, 320)), ("linnr",
            ("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
 auto_split = ops._auto_split_k
 configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
-SHAPES += [("conv", (16, 16, 16, 640, 640)), ("lin", (1024, 1280, 1280)), ("conv", (16, 16, 16, 1920, 1280))]
+SHAPES += [("convout", (8, 512, 512, 128, 3)), ("convout", (16, 64, 64, 320, 4)), ("conv", (16, 16, 16, 640, 640)), ("lin", (1024, 1280, 1280)), ("conv", (16, 16, 16, 1920, 1280))]
 if os.environ.get("CONFIGS"):      # CONFIGS=256:8,128:4  -> (tile_m, split) pairs; SHAPE=<substring of the shape tuple> filters
     configs = [(None, c.split(":")[1], c.split(":")[0]) for c in os.environ["CONFIGS"].split(",")]
 if os.environ.get("SHAPE"):
@@ -39,11 +39,11 @@ for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in confi
         continue
     tn = 128 if tile == "128" else None
     ops._auto_split_k = (lambda m, n, k, t=128, s_=split: min(int(s_), k // 128)) if split else auto_split
-    if kind == "conv":
+    if kind in ("conv", "convout"):
         b, h, w, cin, cout = a
         x = torch.randn(b, h, w, cin, device=dev).to(BF16)
         pw = ops.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=dev) * 0.02, torch.randn(cout, device=dev), tile_n=tn)
-        fn = lambda: ops.conv3x3(x, pw)
+        fn = (lambda: ops.conv3x3(x, pw, out_nchw_f32=True)) if kind == "convout" else (lambda: ops.conv3x3(x, pw))
         flops = 2 * b * h * w * cout * 9 * cin
     elif kind == "geglu":
         m, inner, k = a
