@@ -130,8 +130,9 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype):
         tr, ops.TRACE = ops.TRACE, None
         return [(k, f, e0.elapsed_time(e1) * 1e-3, sk, shp) for k, f, e0, e1, sk, shp in tr]
 
-    collect(lambda: model.apply_model(x_in, ts, c_in))       # warm
-    un = collect(lambda: model.apply_model(x_in, ts, c_in))
+    # (cfg_pairs=True: the launch population of the timed DDIM loop, whose sampler passes the same hint)
+    collect(lambda: model.apply_model(x_in, ts, c_in, cfg_pairs=True))       # warm
+    un = collect(lambda: model.apply_model(x_in, ts, c_in, cfg_pairs=True))
     de = collect(lambda: model.decode_first_stage(x_T))
     out = {}
     for kind in ("conv3x3", "linear", "attention", "groupnorm", "layernorm"):
@@ -303,7 +304,7 @@ def main():
                                f"{args.ddim_steps} DDIM steps + CFG (UNet batch {2 * B}), decode + uint8; "
                                f"BASELINE.json configs[{1 if B == 1 else 2}]",
                    "global_batch": world * B, "latent": h, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world}",
-                   "parameterization": args.parameterization, "hip_graph": use_graph},
+                   "parameterization": args.parameterization, "hip_graph": use_graph, "cfg_pairs": True},
         "unet_step_ms": None,
         "effective_tflops_per_gpu": value / world * flop_per_image / 1e12 if flop_per_image else None,
         "mfma_frac_end_to_end": value / world * flop_per_image / 1e12 / MFMA_PEAK_TFLOPS if flop_per_image else None,
@@ -320,6 +321,15 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     result["unet_step_ms"] = e0.elapsed_time(e1) / 5
+    # the same CFG batch with the samplers' cfg_pairs hint (rows b and b + B are the same latent and step: the layers in
+    # front of the first cross-attention run once per pair) - what the timed DDIM loop above calls
+    model.apply_model(x_in, ts, c_in, cfg_pairs=True)
+    e0.record()
+    for _ in range(5):
+        model.apply_model(x_in, ts, c_in, cfg_pairs=True)
+    e1.record()
+    torch.cuda.synchronize()
+    result["unet_step_ms_cfg_pairs"] = e0.elapsed_time(e1) / 5
     e0.record()
     model.decode_first_stage(x_T)
     e1.record()

@@ -15,11 +15,15 @@ from .schedule import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
 class DDIMSampler(object):
-    def __init__(self, model, schedule="linear", device=None, hip_graph=False, **kwargs):
+    def __init__(self, model, schedule="linear", device=None, hip_graph=False, cfg_pairs=True, **kwargs):
         """hip_graph=True replays the UNet step from a captured hipGraph (graph.py): worth it when the step is
-        launch-bound (small batch); results are bit-identical to eager launches."""
+        launch-bound (small batch); results are bit-identical to eager launches.
+        cfg_pairs=True tells the UNet that a guidance batch is cat([x, x]) (it is: this sampler builds it), so that the
+        layers in front of the first cross-attention run once per pair (UNetModel._forward_cfg_pairs); False = every
+        row through every layer, as the reference's batch would."""
         super().__init__()
         self.model = model
+        self.cfg_pairs = cfg_pairs
         self._apply = model.apply_model
         if hip_graph:
             from .graph import GraphedApplyModel
@@ -127,7 +131,9 @@ class DDIMSampler(object):
             n_in = 2 * b if cfg else b
             ts = torch.full((n_in,), int(step), device=device, dtype=torch.long)
             x_in = torch.cat([img, img]) if cfg else img
-            model_out = self._apply(x_in, ts, c_in)           # ONE UNet forward, batch 2B with CFG
+            # ONE UNet forward, batch 2B with CFG (cfg_pairs: rows b and b + B are the same latent and step - the UNet
+            # computes what precedes its first cross-attention once per pair)
+            model_out = self._apply(x_in, ts, c_in, cfg_pairs=True) if (cfg and self.cfg_pairs) else self._apply(x_in, ts, c_in)
             sigma = float(self.ddim_sigmas[index])
             noise = torch.randn_like(img) * temperature if sigma > 0 else None
             img, pred_x0 = ops.ddim_step(

@@ -18,34 +18,35 @@ class GraphedApplyModel:
         self._graph = None
         self._x = self._t = self._out = self._cond = self._held = None
 
-    def _capture(self, x, t, cond):
+    def _capture(self, x, t, cond, cfg_pairs=False):
         self._x, self._t, self._cond = x.clone(), t.clone(), cond
+        kw = {"cfg_pairs": True} if cfg_pairs else {}
         # warm-up on a side stream: packs weights, fills the cross-attention K/V cache, sets kernel attributes -
         # everything that must not happen inside a capture
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self.model.apply_model(self._x, self._t, self._cond)
+                self.model.apply_model(self._x, self._t, self._cond, **kw)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._out = self.model.apply_model(self._x, self._t, self._cond)
+            self._out = self.model.apply_model(self._x, self._t, self._cond, **kw)
         # the captured launches hold raw pointers into the packed weights and the cached cross-attention K/V of the
         # UNet: keep both alive for as long as this graph is, whatever later eager calls do to the model's caches
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         self._held = (getattr(unet, "_pack", None), getattr(unet, "_ctx_cache", None))
         self._gen = getattr(unet, "_generation", 0)
 
-    def __call__(self, x, t, cond):
+    def __call__(self, x, t, cond, cfg_pairs=False):
         if isinstance(cond, (dict, list, tuple)):
             return self.model.apply_model(x, t, cond)            # only the plain cross-attention form is captured
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         key = (tuple(x.shape), x.dtype, tuple(t.shape), cond.data_ptr(), tuple(cond.shape), cond._version,
-               getattr(unet, "_generation", 0))       # new weights (load_state_dict / .to()) -> re-capture
+               getattr(unet, "_generation", 0), bool(cfg_pairs))       # new weights (load_state_dict / .to()) -> re-capture
         if key != self._key:
-            self._capture(x, t, cond)
+            self._capture(x, t, cond, cfg_pairs)
             self._key = key
         self._x.copy_(x)
         self._t.copy_(t)

@@ -381,17 +381,21 @@ class UNetModel(nn.Module):
             sk = h
         return ops.conv3x3(n2, e["conv2"], res=sk)
 
-    def _transformer(self, pk, st, h, kv, nk):
+    def _transformer(self, pk, st, h, kv, nk, pair_prefix=False):
+        """pair_prefix: `h` holds ONE row per classifier-free-guidance pair (see _forward_cfg_pairs); the rows are
+        duplicated right in front of the first cross-attention, the first op that sees the context."""
         e = pk[id(st)]
         b, hh, ww, c = h.shape
         n = hh * ww
         xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False)
         t = ops.linear(xn.reshape(b * n, c), e["pin"])
-        for be in e["blocks"]:
+        for bi, be in enumerate(e["blocks"]):
             ci, heads = be["c"], be["heads"]
             qkv = ops.linear(t, be["qkv1"], ln=be["ln1"])
             a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
             t = ops.linear(a, be["o1"], res=t)
+            if pair_prefix and bi == 0:
+                t, h, b = torch.cat([t, t]), torch.cat([h, h]), 2 * b
             q2 = ops.linear(t, be["q2"], ln=be["ln2"])
             ko = be["kv_off"]
             a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
@@ -419,9 +423,41 @@ class UNetModel(nn.Module):
         return h
 
     @torch.no_grad()
-    def forward(self, x, time_steps=None, context=None, label=None, timesteps=None, y=None, **kwargs):
+    def _cfg_prefix_blocks(self):
+        """The blocks in front of the first cross-attention, if the model starts the way SD's does: conv_in, then
+        [ResBlock, SpatialTransformer]."""
+        if len(self.input_blocks) < 2:
+            return None
+        b0, b1 = list(self.input_blocks[0]), list(self.input_blocks[1])
+        if len(b0) == 1 and isinstance(b0[0], nn.Conv2d) and len(b1) == 2 and isinstance(b1[0], ResBlock) and \
+                isinstance(b1[1], SpatialTransformer):
+            return b0, b1
+        return None
+
+    def _forward_cfg_pairs(self, pk, x, emb_all, kv, nk):
+        """The first two input blocks for a classifier-free-guidance batch x = cat([z, z]), t = cat([t, t]),
+        context = cat([uc, c]) (what DDIMSampler / PLMSSampler build, ddim.py:184-186 upstream): rows b and b + B/2 are the
+        same latent at the same time step and differ in the context only, so everything in front of the first
+        cross-attention - conv_in, the first ResBlock, GroupNorm + proj_in, the first self-attention and its output
+        projection - is the same computation twice.  It runs once, on B/2 rows, and is duplicated where the context
+        enters.  Exact: the duplicated rows are what the full batch would have computed, up to the fp32 summation order
+        of a GEMM plan that depends on the row count.  Returns (h, [skip tensors of the two blocks]) at full batch."""
+        b0, b1 = self._cfg_prefix_blocks()
+        half = x.shape[0] // 2
+        emb_h = emb_all[:half]
+        h = ops.nchw_to_nhwc(x[:half].float().contiguous(), dtype=self.compute_dtype)
+        h0 = ops.conv3x3(h, pk[id(b0[0])])
+        r = self._res_block(pk, b1[0], h0, None, emb_h)
+        h1 = self._transformer(pk, b1[1], r, kv, nk, pair_prefix=True)
+        return h1, [torch.cat([h0, h0]), h1]
+
+    @torch.no_grad()
+    def forward(self, x, time_steps=None, context=None, label=None, timesteps=None, y=None, cfg_pairs=False, **kwargs):
         """x [B, C, h, w] (fp32/fp16/bf16 NCHW), time_steps int64 [B], context [B, Nk, context_dim]
-        -> eps / v prediction, same shape and dtype as x (openai_model.py:940-1018)."""
+        -> eps / v prediction, same shape and dtype as x (openai_model.py:940-1018).
+        cfg_pairs=True is the caller's promise that x[B/2:] == x[:B/2] and time_steps[B/2:] == time_steps[:B/2] (a
+        classifier-free-guidance batch): the part of the network in front of the first cross-attention then runs on
+        B/2 rows (_forward_cfg_pairs)."""
         time_steps = time_steps if time_steps is not None else timesteps
         label = label if label is not None else y
         assert (label is not None) == (self.num_classes is not None), \
@@ -440,9 +476,13 @@ class UNetModel(nn.Module):
         kv = self._context_kv(pk, context)
         nk = context.shape[1]
 
-        h = ops.nchw_to_nhwc(x.float().contiguous(), dtype=self.compute_dtype)
-        hs = []
-        for blk in self.input_blocks:
+        if cfg_pairs and bsz % 2 == 0 and bsz >= 2 and self._cfg_prefix_blocks() is not None:
+            h, hs = self._forward_cfg_pairs(pk, x, emb_all, kv, nk)
+            rest = list(self.input_blocks)[2:]
+        else:
+            h = ops.nchw_to_nhwc(x.float().contiguous(), dtype=self.compute_dtype)
+            hs, rest = [], self.input_blocks
+        for blk in rest:
             h = self._run_block(pk, blk, h, None, emb_all, kv, nk)
             hs.append(h)
         h = self._run_block(pk, self.middle_block, h, None, emb_all, kv, nk)

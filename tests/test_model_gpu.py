@@ -95,6 +95,32 @@ def test_tiny_decoder_vs_oracle(dev, mode, dt):
         assert rel_err(img, gold) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_cfg_pairs_prefix_equals_full_batch(dev, dt):
+    """UNetModel.forward(cfg_pairs=True): for a guidance batch cat([z, z]) / cat([t, t]) / cat([uc, c]) the layers in
+    front of the first cross-attention run once per pair.  Same result as pushing every row through every layer, up to
+    the fp32 summation order of GEMM plans that depend on the row count (the half batch runs the tiled kernel +
+    sdmi_layernorm where the full batch runs the panel kernel with the LayerNorm fused): the two 16-bit runs differ by
+    about their own rounding noise - and sit at the same distance from the fp32 oracle."""
+    from oracle import model as OM
+    from stablediffusion_amd.unet import UNetModel
+    m, sd = build(UNetModel, policy(synth.SD2_UNET, dt), "unet.", dev)
+    z = synth.synth_input("pairs_z", (2, 4, 64, 64))
+    ctx = synth.synth_input("pairs_ctx", (4, 77, 1024))
+    t = torch.tensor([761, 12])
+    x_in, t_in = torch.cat([z, z]).to(dev), torch.cat([t, t]).to(dev)
+    full = m(x_in, t_in, ctx.to(dev))
+    pairs = m(x_in, t_in, ctx.to(dev), cfg_pairs=True)
+    e = rel_err(pairs, full)
+    print(f"[parity] sd2 unet h64 cfg_pairs vs full batch ({dt}): rel_err {e:.3e}")
+    assert e < (4e-3 if dt == "fp16" else 2.5e-2)
+    with torch.no_grad():
+        ref = OM.unet_forward(sd, synth.SD2_UNET, z[1:], t[1:], ctx[3:])       # row 3 = (z[1], t[1], ctx[3])
+    e_full, e_pairs = rel_err(full[3:], ref), rel_err(pairs[3:], ref)
+    print(f"[parity] ... row 3 vs fp32 oracle: full {e_full:.3e}, cfg_pairs {e_pairs:.3e}")
+    assert e_pairs < TOL[dt] and e_full < TOL[dt]
+
+
 @pytest.mark.parametrize("mode", ["reference", "standard"])
 def test_tiny_decoder_fp32_mode(dev, mode):
     """fp32 mode of the VAE decoder (compute_dtype = torch.float32: fp32 activations, contractions on exact three-way
@@ -297,7 +323,7 @@ def test_plms_matches_oracle(dev, dt):
     if dt == HEADLINE:
         forced = PLMSSampler(model)
         with torch.no_grad():
-            forced._apply = lambda x, t, cond: fn(x.cpu(), t.cpu(), cond.cpu()).to(dev)
+            forced._apply = lambda x, t, cond, **kw: fn(x.cpu(), t.cpu(), cond.cpu()).to(dev)
             out_tf, _ = forced.sample(**kw)
         e_tf = rel_err(out_tf, ref)
         print(f"[parity] plms tiny 10-step, model evaluations teacher-forced by the oracle: latent rel_err {e_tf:.3e}")
