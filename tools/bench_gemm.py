@@ -26,6 +26,9 @@ SHAPES += [("linnr", (65536, 960, 320)), ("linnr", (65536, 320, 320)), ("linnr",
            ("geglu", (65536, 1280, 320)), ("geglu", (16384, 2560, 640)), ("geglu", (4096, 5120, 1280))]
 auto_split = ops._auto_split_k
 configs = [(os.environ.get("TILE_N"), os.environ.get("SPLITK"), os.environ.get("TILE_M", "0"))]
+SHAPES += [("linnr", (65536, 320, 640)), ("linnr", (65536, 320, 960)), ("lin", (16384, 640, 2560)), ("linnr", (16384, 640, 1280)),
+           ("linnr", (16384, 640, 1920)), ("linnr", (4096, 3840, 1280)), ("lin", (4096, 1280, 5120)), ("linnr", (4096, 1280, 2560)),
+           ("linnr", (4096, 1280, 1920)), ("linnr", (1024, 1280, 2560)), ("linnr", (1024, 3840, 1280)), ("lin", (1024, 1280, 5120))]
 SHAPES += [("convout", (8, 512, 512, 128, 3)), ("convout", (16, 64, 64, 320, 4)), ("conv", (16, 16, 16, 640, 640)), ("lin", (1024, 1280, 1280)), ("conv", (16, 16, 16, 1920, 1280))]
 if os.environ.get("CONFIGS"):      # CONFIGS=256:8,128:4  -> (tile_m, split) pairs; SHAPE=<substring of the shape tuple> filters
     configs = [(None, c.split(":")[1], c.split(":")[0]) for c in os.environ["CONFIGS"].split(",")]
