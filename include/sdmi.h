@@ -117,7 +117,7 @@ typedef struct sdmi_gemm_args {
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
-/* 1 if sdmi_gemm would run (algo 0) / can run (algo 2) this problem on the A-panel-stationary kernel, else 0. */
+/* 1 if this problem can run on the A-panel-stationary kernel (algo 2, or algo 0 with ln_gamma set), else 0. */
 int sdmi_gemm_panel_applies(const sdmi_gemm_args* args);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */

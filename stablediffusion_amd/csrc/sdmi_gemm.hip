@@ -152,11 +152,22 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         const int st = sdmi_conv_narrow_launch(p, s);
         if (st != 0) return st < 0 ? st : SDMI_OK;
     }
-    if (p.algo != 1) {       // short K, many rows: the A-panel-stationary kernel (sdmi_gemm_panel.h)
+    // The A-panel-stationary kernel (sdmi_gemm_panel.h): picked when a LayerNorm rides along (it is the kernel that holds
+    // whole rows), or on request (algo 2).  Without the LayerNorm the tiled kernel's 256-row tile is the faster one on the
+    // same problems (65536 x 320 x 320 + residual: 34 us against 40; N = 960: 70 against 79), so algo 0 stays there.
+#ifndef SDMI_PANEL_AUTO_ALWAYS
+#define SDMI_PANEL_AUTO_ALWAYS 0      // A/B: 1 = algo 0 takes the panel kernel wherever it applies (the round-2 mid-state)
+#endif
+    if (SDMI_PANEL_AUTO_ALWAYS && p.algo == 0 && p.ln_gamma == nullptr) {
         const int st = sdmi_gemm_panel_launch(p, s);
         if (st != 0) return st < 0 ? st : SDMI_OK;
-        if (p.algo == 2 || p.ln_gamma != nullptr) return SDMI_ERR_BAD_ARG;      // (the tiled kernel never holds a whole row)
     }
+    if (p.algo == 2 || (p.algo == 0 && p.ln_gamma != nullptr)) {
+        const int st = sdmi_gemm_panel_launch(p, s);
+        if (st != 0) return st < 0 ? st : SDMI_OK;
+        return SDMI_ERR_BAD_ARG;      // (the tiled kernel never holds a whole row)
+    }
+    if (p.ln_gamma != nullptr) return SDMI_ERR_BAD_ARG;
     // dynamic-LDS attribute of every instantiation, once per process (thread-safe; a refusal is reported, not ignored)
     static std::once_flag attr_once;
     static int attr_status = SDMI_OK;

@@ -49,7 +49,10 @@ extern "C" int sdmi_gemm_panel_applies(const sdmi_gemm_args* a) {
 int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s) {
     if (!panel_applies(p)) return 0;
     const int64_t n_w = p.geglu ? 2 * p.N : p.N;
-    const int which = p.geglu ? 2 : (n_w >= 960 ? 1 : 0);
+#ifndef SDMI_PANEL_L_MIN_N
+#define SDMI_PANEL_L_MIN_N 960
+#endif
+    const int which = p.geglu ? 2 : (n_w >= SDMI_PANEL_L_MIN_N ? 1 : 0);
     static std::once_flag once;
     static int attr_status = SDMI_OK;
     std::call_once(once, [] {

@@ -213,12 +213,10 @@ def _plan_gemm(m, n_w, k, tile_n=_BN):
     splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to tools/bench_gemm.py SWEEP=1 on
     MI355X (predicted vs measured within ~10% on the UNet conv shapes)."""
     nk = k // _BK
-    if nk <= 5 and math.ceil(m / 128) * math.ceil(n_w / tile_n) >= 2 * _CUS:
-        # K <= 320, many tiles (where the panel kernel does not apply): 128-row tile with a two-stage ring = two blocks
-        # per CU, so the (relatively long) epilogue of one block overlaps the main loop of the other.  (Round 1 used
-        # this up to K = 640; re-measured in round 2, with the 16-byte epilogue the 256-row tile is 4..26 % faster
-        # there: 16384 x 640 x 640 30.6 -> 23.9 us, 16384 x 1920 x 640 77 -> 57 us, GEGLU 16384 x 5120 x 640 141 -> 137.)
-        return (128, 1, 2)
+    # (Rounds 1 - 2 sent short K with many tiles to the two-stage 128-row variant - two blocks per CU, one block's epilogue
+    # under the other's main loop.  Re-measured at the end of round 2 the 256-row tile beats it on every such shape:
+    # 65536 x 320 x 320 37.4 -> 27.6 us, 16384 x 640 x 640 30.6 -> 23.9, 16384 x 1920 x 640 77 -> 57, GEGLU
+    # 16384 x 5120 x 640 141 -> 137; the variant stays reachable through sdmi_gemm_args.stages = 2.)
     best, best_cost = (128, 1, 3), None
     for tile_m, step_us in ((256, 1.12 * tile_n / 160), (128, 0.67 * tile_n / 160)):
         tiles = math.ceil(m / tile_m) * math.ceil(n_w / tile_n)

@@ -418,8 +418,8 @@ def test_panel_gemm_k320(dev, dt, m, n, bias, res):
     tol = 8e-3 if dt == BF16 else 1.5e-3
     assert rel_err(outs[2], ref) < tol and rel_err(outs[1], ref) < tol
     assert rel_err(outs[2], outs[1].float()) < tol
-    auto = ops.linear(x.to(dt), pw, res=r.to(dt) if res else None)       # what the library picks on its own
-    assert torch.equal(auto, outs[2])
+    auto = ops.linear(x.to(dt), pw, res=r.to(dt) if res else None)       # what the library picks on its own: the tiled kernel
+    assert torch.equal(auto, outs[1])                                    # (the panel kernel only when a LayerNorm rides along)
 
 
 @pytest.mark.parametrize("dt", [BF16, torch.float16])
