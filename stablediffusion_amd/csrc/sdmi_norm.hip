@@ -351,7 +351,10 @@ static int groupnorm_launch(const void* x1, const void* x2, int32_t C1, int32_t 
                             void* stream) {
     const int C = C1 + C2;
     // Small images (<= 1024 pixels): one slab per image and one fused launch; else P-pixel slabs and two launches.
-    const bool fused = hw <= 1024;
+#ifndef SDMI_GN_FUSED_MAX_HW
+#define SDMI_GN_FUSED_MAX_HW 1024
+#endif
+    const bool fused = hw <= SDMI_GN_FUSED_MAX_HW;
     const int64_t P = fused ? hw : gn_slab_pixels(hw);
     const int nslab = (int)((hw + P - 1) / P);
     // channel chunks (whole groups, 16-byte aligned) until the grid can fill the chip
