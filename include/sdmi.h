@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -96,7 +96,10 @@ typedef struct sdmi_gemm_args {
     int32_t batch, split_k;
     int32_t dtype;                      /* sdmi_dtype of A, A2, W, res and of out when out_kind == 0 */
     float alpha;
-    int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it */
+    int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it.  256 = the
+                                           256 x 256 x 32 tile (more FLOP per byte moved into LDS: for long K with N_w a
+                                           multiple of 256): the caller vouches that W has N_w rounded up to 256 rows, and
+                                           sdmi_gemm_wide_applies() must hold - SDMI_ERR_BAD_ARG otherwise */
     int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 */
     int32_t asym_pad;                   /* mode 1: 0 = zero pad 1 on every side; 1 = pad bottom/right only - the VAE
                                            encoder's DownSample, F.pad(x, (0,1,0,1)) + conv stride 2 (model.py:87,99-102) */
@@ -119,6 +122,10 @@ typedef struct sdmi_gemm_args {
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
 /* 1 if this problem can run on the A-panel-stationary kernel (algo 2, or algo 0 with ln_gamma set), else 0. */
 int sdmi_gemm_panel_applies(const sdmi_gemm_args* args);
+/* 1 if this problem can run on the 256 x 256 x 32 tile (tile_n = 256): whole 64-deep k-tiles (mode 0: no K padding in
+   A; mode 1: Cin % 64 == 0), and either split_k > 1 or a plain 16-bit row-major epilogue (no GEGLU, N % 8 == 0, column
+   bias, 16-byte aligned out / res with ld % 8 == 0).  Has no say on whether W is padded to 256 rows. */
+int sdmi_gemm_wide_applies(const sdmi_gemm_args* args);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);

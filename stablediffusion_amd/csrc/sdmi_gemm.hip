@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
 SDMI_GEMM_UNIT_DECL(m0_bf16) SDMI_GEMM_UNIT_DECL(m0_f16) SDMI_GEMM_UNIT_DECL(m1_bf16) SDMI_GEMM_UNIT_DECL(m1_f16)
 #undef SDMI_GEMM_UNIT_DECL
 
+int sdmi_gemm_wide_attrs_bf16();                                         // sdmi_gemm_wide_*.hip
+int sdmi_gemm_wide_attrs_f16();
+void sdmi_gemm_wide_launch_bf16(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_wide_launch_f16(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s);      // sdmi_gemm_panel.hip
 int sdmi_conv_narrow_launch(const sdmi_gemm_args& p, hipStream_t s);     // sdmi_conv_narrow.hip
 
@@ -84,10 +88,35 @@ static int64_t slab_ld(int64_t N_w, int tile_n) { return (N_w + tile_n - 1) / ti
 
 extern "C" int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k) {
     if (split_k <= 1) return 0;
-    // enough for either column tile (128 or 160)
-    const int64_t ldw = slab_ld(N_w, 128) > slab_ld(N_w, 160) ? slab_ld(N_w, 128) : slab_ld(N_w, 160);
+    // enough for any column tile (128, 160 or 256)
+    int64_t ldw = slab_ld(N_w, 128) > slab_ld(N_w, 160) ? slab_ld(N_w, 128) : slab_ld(N_w, 160);
+    if (slab_ld(N_w, 256) > ldw) ldw = slab_ld(N_w, 256);
     return (int64_t)split_k * M * ldw * (int64_t)sizeof(float);
 }
+
+// The 256 x 256 x 32 tile (sdmi_gemm_wide.h) runs whole k-tiles from plain row / tap pointers and has two epilogues: the
+// 16-bit fast path and the split-K slabs.
+static bool wide_applies(const sdmi_gemm_args& p) {
+    const int batch = p.batch > 0 ? p.batch : 1;
+    const int split = p.split_k > 0 ? p.split_k : 1;
+    if (p.ln_gamma != nullptr || p.algo == 2) return false;
+    if (p.tile_m != 0 && p.tile_m != 256) return false;
+    if (p.stages != 0 && p.stages != 3) return false;
+    if (p.K % 64 != 0) return false;
+    if (p.mode == 0) {
+        if (p.k_valid != 0 && p.k_valid != p.K) return false;
+    } else {
+        if (p.Cin % 64 != 0 || p.Cin > ZERO_ELEMS || p.K != 9 * (int64_t)p.Cin) return false;
+    }
+    if (split > 1) return true;
+    if (p.geglu || p.out_kind != 0 || (p.N & 7) != 0 || p.bias_per_row || (p.ld_out & 7) != 0) return false;
+    if (p.res != nullptr && ((p.ld_res & 7) != 0 || p.res_f32)) return false;
+    if ((((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0) return false;
+    if (batch > 1 && (((p.stride_out | p.stride_res) & 7) != 0)) return false;
+    return true;
+}
+
+extern "C" int sdmi_gemm_wide_applies(const sdmi_gemm_args* a) { return a != nullptr && wide_applies(*a) ? 1 : 0; }
 
 extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->out == nullptr) return SDMI_ERR_BAD_ARG;
@@ -132,11 +161,12 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     p.split_k = split;
     const int64_t n_w = p.geglu ? 2 * p.N : p.N;
     const int BN = p.tile_n == 0 ? 128 : p.tile_n;
-    if (BN != 128 && BN != 160) return SDMI_ERR_BAD_ARG;
+    if (BN != 128 && BN != 160 && BN != 256) return SDMI_ERR_BAD_ARG;
     if (BN == 160 && p.geglu) return SDMI_ERR_BAD_ARG;      // GEGLU pairs 16-column blocks inside a wave
     if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
     if (p.stages != 0 && p.stages != 2 && p.stages != 3) return SDMI_ERR_BAD_ARG;
-    const int BM = p.tile_m != 0 ? p.tile_m : pick_tile_m(p.M, n_w, BN, batch);
+    if (BN == 256 && !wide_applies(p)) return SDMI_ERR_BAD_ARG;
+    const int BM = BN == 256 ? 256 : p.tile_m != 0 ? p.tile_m : pick_tile_m(p.M, n_w, BN, batch);
     const int64_t tiles_m = (p.M + BM - 1) / BM, tiles_n = (n_w + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
     if (split > 1) {
@@ -176,14 +206,16 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
                                  sdmi_gemm_unit_attrs_m1_f16};
         for (int i = 0; i < 4; ++i)
             if (fns[i]() != SDMI_OK) attr_status = SDMI_ERR_LAUNCH;
+        if (sdmi_gemm_wide_attrs_bf16() != SDMI_OK || sdmi_gemm_wide_attrs_f16() != SDMI_OK) attr_status = SDMI_ERR_LAUNCH;
     });
     if (attr_status != SDMI_OK) return attr_status;
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (p.mode == 0) (f16 ? sdmi_gemm_unit_launch_m0_f16 : sdmi_gemm_unit_launch_m0_bf16)(wide, variant, grid, s, p);
-    else             (f16 ? sdmi_gemm_unit_launch_m1_f16 : sdmi_gemm_unit_launch_m1_bf16)(wide, variant, grid, s, p);
+    if (BN == 256)        (f16 ? sdmi_gemm_wide_launch_f16 : sdmi_gemm_wide_launch_bf16)(p.mode, grid, s, p);
+    else if (p.mode == 0) (f16 ? sdmi_gemm_unit_launch_m0_f16 : sdmi_gemm_unit_launch_m0_bf16)(wide, variant, grid, s, p);
+    else                  (f16 ? sdmi_gemm_unit_launch_m1_f16 : sdmi_gemm_unit_launch_m1_bf16)(wide, variant, grid, s, p);
     SDMI_CHECK_LAUNCH();
     if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);

@@ -126,7 +126,10 @@ __device__ __forceinline__ void wait_dma(int keep_stages) {
 // instead of 8 and 32.  P0 = first block of the first pair, chosen by the caller so every pair starts on a 64-byte
 // boundary; blocks left over (TN odd) keep the 8-byte form.  All residual / embedding loads of a row block are
 // requested before the first one is consumed.
-template <int DT, int TN, int MI, int P0>
+#ifndef SDMI_RES_HOIST
+#define SDMI_RES_HOIST 1      // A/B (tools/ab_build.sh): 0 = residual requested row block by row block everywhere
+#endif
+template <int DT, int TN, int MI, int P0, bool HOIST = (SDMI_RES_HOIST != 0)>
 __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], int64_t mrow, int64_t ncol_w,
                                                 int fq, int64_t zoff_out, int64_t zoff_res) {
     const int odd = fq & 1;
@@ -143,6 +146,36 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
     }
     const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
     unsigned short* const outp = reinterpret_cast<unsigned short*>(p.out) + zoff_out;
+    // The residual of ALL row blocks is requested before the first one is consumed: one trip to memory per wave instead
+    // of one per row block.  In the step the residual is cold (written several kernels earlier, long evicted from the
+    // Infinity Cache): 65536 x 320 x 320 + residual on operands that are not cache-warm 45 -> 38 us, 16384 x 640 x 640
+    // 30.3 -> 26.7, 65536 x 960 x 320 120 -> 102 (tools/bench_gemm.py ROTATE=8).  Touching the residual tile's lines ahead
+    // of the main loop as well (three scattered LDS-DMA instructions per wave into a dump area) was measured slower
+    // (38 -> 44 us): 64 lines per instruction cost more in the address path than the late trip they save.  (Each lane reads exactly the elements it later writes, so out == res stays legal.)
+    // (HOIST = false - the two-stage variant, capped at 128 VGPRs - requests them row block by row block.)
+    uint2 rq_all[MI][TN];
+#define SDMI_RES_LOAD_ROWBLOCK(mi)                                                                         \
+    do {                                                                                                   \
+        const int64_t m = mrow + (mi) * 16;                                                                \
+        const bool mval = m < p.M;                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) rq_all[mi][ni] = make_uint2(0u, 0u);             \
+        _Pragma("unroll") for (int ni = P0; ni + 1 < TN; ni += 2) {                                        \
+            uint4 r4 = make_uint4(0u, 0u, 0u, 0u);                                                         \
+            const int64_t n = ncol8 + ni * 16;                                                             \
+            if (mval && n < p.N) r4 = *reinterpret_cast<const uint4*>(resp + m * p.ld_res + n);            \
+            rq_all[mi][ni] = make_uint2(r4.x, r4.y);      /* (8-columns-per-lane order: swapped below) */  \
+            rq_all[mi][ni + 1] = make_uint2(r4.z, r4.w);                                                   \
+        }                                                                                                  \
+        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) {                                                \
+            const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));                              \
+            if (single && mval && nval[ni])                                                                \
+                rq_all[mi][ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);   \
+        }                                                                                                  \
+    } while (0)
+    if (HOIST && p.res != nullptr) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) SDMI_RES_LOAD_ROWBLOCK(mi);
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int64_t m = mrow + mi * 16;
@@ -150,22 +183,15 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
         uint2 rq[TN];
         f32x4 eq[TN];
         if (p.res != nullptr) {
+            if (!HOIST) SDMI_RES_LOAD_ROWBLOCK(mi);
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) rq[ni] = make_uint2(0u, 0u);
+            for (int ni = 0; ni < TN; ++ni) rq[ni] = rq_all[mi][ni];
 #pragma unroll
             for (int ni = P0; ni + 1 < TN; ni += 2) {
-                uint4 r4 = make_uint4(0u, 0u, 0u, 0u);
-                const int64_t n = ncol8 + ni * 16;
-                if (mval && n < p.N) r4 = *reinterpret_cast<const uint4*>(resp + m * p.ld_res + n);
-                const auto sx = __builtin_amdgcn_permlane16_swap(r4.x, r4.z, false, false);
-                const auto sy = __builtin_amdgcn_permlane16_swap(r4.y, r4.w, false, false);
+                const auto sx = __builtin_amdgcn_permlane16_swap(rq_all[mi][ni].x, rq_all[mi][ni + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(rq_all[mi][ni].y, rq_all[mi][ni + 1].y, false, false);
                 rq[ni] = make_uint2(sx[0], sy[0]);
                 rq[ni + 1] = make_uint2(sx[1], sy[1]);
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));
-                if (single && mval && nval[ni]) rq[ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);
             }
         }
         if (p.emb != nullptr) {
@@ -211,6 +237,8 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
         }
     }
 }
+
+#undef SDMI_RES_LOAD_ROWBLOCK
 
 // One workgroup = 8 waves (4 x 2), block tile (64*MI) x (32*TN) x 64, one workgroup per CU (two waves per SIMD),
 // 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
@@ -516,8 +544,8 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)(2 * zoff_out) | (uintptr_t)(2 * zoff_res)) & 15) == 0) {
         const int64_t mrow = m0 + wm * (MI * 16) + frow, ncol_w = n0 + wn * (TN * 16);
         // pairs start on even 16-column blocks of the output: with 5 blocks per wave the odd wave column shifts by one
-        if ((TN & 1) && (wn & 1)) epilogue_rows16<DT, TN, MI, 1>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
-        else                      epilogue_rows16<DT, TN, MI, 0>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
+        if ((TN & 1) && (wn & 1)) epilogue_rows16<DT, TN, MI, 1, (SDMI_RES_HOIST != 0) && NST != 2>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
+        else                      epilogue_rows16<DT, TN, MI, 0, (SDMI_RES_HOIST != 0) && NST != 2>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
         return;
     }
     if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row && !p.res_f32) {

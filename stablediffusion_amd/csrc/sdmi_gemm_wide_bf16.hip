@@ -1,0 +1,3 @@
+// sdmi_gemm instantiation unit: the 256 x 256 x 32 tile (sdmi_gemm_wide.h), bf16 operands, both modes.
+#include "sdmi_gemm_wide.h"
+SDMI_GEMM_WIDE_UNIT(0, bf16)

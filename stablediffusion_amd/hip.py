@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 9     # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 10    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "sdmi_gemm_tile_m": (C.c_int32, [C.c_int64, C.c_int64, C.c_int32]),
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "sdmi_gemm_panel_applies": (C.c_int, [C.POINTER(GemmArgs)]),
+    "sdmi_gemm_wide_applies": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "sdmi_pack_tile_n": (_i32, [_i64, _i32]),
     "sdmi_pack_linear_k": (_i64, [_i64, _i32]),

@@ -202,22 +202,45 @@ def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
 
 FORCE_ALGO = 0        # development aid / tests: sdmi_gemm_args.algo (0 auto, 1 tiled kernel, 2 panel kernel)
 FORCE_TILE_M = 0      # development aid (tools/bench_gemm.py): 0 = the library picks the row tile, else 128 | 256
+FORCE_WIDE = 0        # development aid: 1 = the 256 x 256 x 32 tile wherever it applies
+WIDE_TILE = True      # False: _plan_gemm never picks the 256 x 256 x 32 tile (A/B, tests)
 
 _CUS = 256            # MI355X compute units; the GEMM kernel runs one 8-wave block per CU at a time
 
 
+def _wide_wins(m, n_w, nk, tile_n):
+    """Whether the 256 x 256 x 32 tile (sdmi_gemm_wide.h) beats both row tiles of the tiled kernel, unsplit.  Times in us
+    from the measured step costs (tools/bench_gemm.py WIDE=0|1): 0.97 per 32-deep step for the wide tile, 1.12 | 1.07
+    per 64-deep step of the 256 x 160 | 256 x 128 tile, 0.67 | 0.63 for the 128-row tiles, and the fixed per-block
+    costs those sweeps show for an unsplit launch.  It needs a launch that fills the chip with its own, fewer tiles:
+    4096 x 3840 x 1280 55 -> 43 us, 8192^3 1087 -> 990, the decoder's 512- and 256-channel convs +7..9 %; below ~200
+    tiles (M = 4096 x N = 1280: 80) it loses to split-K on the smaller tiles and is not considered."""
+    tiles_w = math.ceil(m / 256) * math.ceil(n_w / 256)
+    if tiles_w < 200 or nk < 16:      # (short K: not measured)
+        return False
+    t_wide = math.ceil(tiles_w / _CUS) * (2 * nk + 10) * 0.97
+    cols = math.ceil(n_w / tile_n)
+    t_256 = math.ceil(math.ceil(m / 256) * cols / _CUS) * (nk + 9) * (1.12 if tile_n == 160 else 1.07)
+    t_128 = math.ceil(math.ceil(m / 128) * cols / _CUS) * (nk + 7.6) * (0.67 if tile_n == 160 else 0.63)
+    return t_wide < 0.95 * min(t_256, t_128)
+
+
 @functools.lru_cache(maxsize=None)
-def _plan_gemm(m, n_w, k, tile_n=_BN):
-    """(tile_m, split_k, stages) from a small occupancy model, in microseconds.  A launch of B blocks puts ceil(B/256)
-    blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed prologue/epilogue;
-    splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to tools/bench_gemm.py SWEEP=1 on
-    MI355X (predicted vs measured within ~10% on the UNet conv shapes)."""
+def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False):
+    """(tile_m, split_k, stages, tile_n) from a small occupancy model, in microseconds.  A launch of B blocks puts
+    ceil(B/256) blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed
+    prologue/epilogue; splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to
+    tools/bench_gemm.py sweeps on MI355X (predicted vs measured within ~10% on the UNet conv shapes).
+    wide_ok: the 256 x 256 x 32 tile (tile_n 256) may be chosen - the weight is padded to 256 rows and the epilogue is
+    one it has; _wide_wins decides."""
     nk = k // _BK
+    if wide_ok and _wide_wins(m, n_w, nk, tile_n):
+        return (256, 1, 3, 256)
     # (Rounds 1 - 2 sent short K with many tiles to the two-stage 128-row variant - two blocks per CU, one block's epilogue
     # under the other's main loop.  Re-measured at the end of round 2 the 256-row tile beats it on every such shape:
     # 65536 x 320 x 320 37.4 -> 27.6 us, 16384 x 640 x 640 30.6 -> 23.9, 16384 x 1920 x 640 77 -> 57, GEGLU
     # 16384 x 5120 x 640 141 -> 137; the variant stays reachable through sdmi_gemm_args.stages = 2.)
-    best, best_cost = (128, 1, 3), None
+    best, best_cost = (128, 1, 3, tile_n), None
     for tile_m, step_us in ((256, 1.12 * tile_n / 160), (128, 0.67 * tile_n / 160)):
         tiles = math.ceil(m / tile_m) * math.ceil(n_w / tile_n)
         for s in range(1, 17):
@@ -230,12 +253,15 @@ def _plan_gemm(m, n_w, k, tile_n=_BN):
             if s > 1:
                 cost += (2 * s + 0.5) * m * n_w * 4 / 12.0e6 + 6.0   # slab write+read (mostly L2/MALL) + the extra launch
             if best_cost is None or cost < best_cost * 0.97:
-                best, best_cost = (tile_m, s, 3), cost
+                best, best_cost = (tile_m, s, 3, tile_n), cost
     return best
 
 
 def _auto_split_k(m, n_w, k, tile_n=_BN):
     return _plan_gemm(m, n_w, k, tile_n)[1]
+
+
+_AUTO_SPLIT_K = _auto_split_k
 
 
 # Optional per-launch instrumentation (bench.py's roofline leg): when TRACE is a list, every sdmi_gemm
@@ -305,8 +331,17 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     n_w = pw.n_out * (2 if pw.geglu else 1)
     a.tile_n = pw.tile_n
     a.algo = FORCE_ALGO
-    a.tile_m, sk, a.stages = _plan_gemm(m, n_w, pw.k, pw.tile_n)
-    sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)      # (separate hook: tests and tools pin it)
+    # the 256 x 256 x 32 tile: only where the weight buffer has the rows for it and the library has the epilogue (asked
+    # with split_k = 1 - the stricter question - so the answer holds whatever split is pinned below)
+    wide_ok = bool(WIDE_TILE and not FORCE_TILE_M and not FORCE_ALGO and pw.w.shape[0] % 256 == 0)
+    if wide_ok:
+        a.tile_n, a.split_k = 256, 1
+        wide_ok = bool(hip.lib().sdmi_gemm_wide_applies(C.byref(a)))
+    a.tile_m, sk, a.stages, a.tile_n = _plan_gemm(m, n_w, pw.k, pw.tile_n, wide_ok)
+    if FORCE_WIDE and wide_ok:
+        a.tile_m, sk, a.tile_n = 256, 1, 256
+    if _auto_split_k is not _AUTO_SPLIT_K or a.tile_n != 256:
+        sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)      # (separate hook: tests and tools pin it)
     if FORCE_TILE_M:
         a.tile_m = FORCE_TILE_M & ~1
         a.stages = 2 if FORCE_TILE_M & 1 else 3         # 129 = 128 rows, two stages

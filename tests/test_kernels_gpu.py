@@ -190,6 +190,80 @@ def test_tall_tile_full_path(dev, monkeypatch):
         assert rel_err(out.permute(0, 3, 1, 2), F.conv2d(xin, q(wt), bias, stride=stride, padding=1)) < 6e-3
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_wide_tile_256x256x32(dev, dt, monkeypatch):
+    """The 256 x 256 x 32 tile (sdmi_gemm_wide.h, tile_n = 256) against the fp32 reference and against the tiled kernel
+    on the same inputs: linear with bias + residual / SiLU, ragged M, concat A, split-K (slices of odd and even
+    length), conv stride 1 / 2 / upsampled with the embedding add.  Tolerance (both comparisons) = the 16-bit output rounding: the two kernels
+    accumulate in the same k order, but the plan may split K for one and not for the other."""
+    ops = _ops()
+    tol = 6e-3 if dt == BF16 else 1.5e-3
+    qd = lambda t: t.to(dt).float()
+    def both(f):
+        monkeypatch.setattr(ops, "FORCE_WIDE", 0)
+        monkeypatch.setattr(ops, "WIDE_TILE", False)
+        tiled = f()
+        monkeypatch.setattr(ops, "FORCE_WIDE", 1)
+        monkeypatch.setattr(ops, "WIDE_TILE", True)
+        wide = f()
+        return tiled, wide
+    for (m, n, k) in ((1000, 512, 320), (300, 256, 64), (520, 1280, 2560)):
+        x, w, b, res = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3), rnd((m, n), dev, 4)
+        pw = ops.pack_linear(w, b, dtype=dt)
+        assert pw.w.shape[0] % 256 == 0
+        tiled, wide = both(lambda: ops.linear(x.to(dt), pw, res=res.to(dt)))
+        assert rel_err(tiled, wide) < tol
+        assert rel_err(wide, F.linear(qd(x), qd(w), b) + qd(res)) < tol
+        tiled, wide = both(lambda: ops.linear(x.to(dt), pw, act=1))
+        assert rel_err(tiled, wide) < tol
+        assert rel_err(wide, F.silu(F.linear(qd(x), qd(w), b))) < tol
+        for sk in (2, 3):
+            if k // 64 < sk:
+                continue
+            monkeypatch.setattr(ops, "_auto_split_k", lambda *a, s_=sk, **kw: s_)
+            tiled, wide = both(lambda: ops.linear(x.to(dt), pw, res=res.to(dt)))
+            monkeypatch.setattr(ops, "_auto_split_k", ops._AUTO_SPLIT_K)
+            assert rel_err(wide, F.linear(qd(x), qd(w), b) + qd(res)) < tol      # (slice boundaries differ from the tiled kernel's)
+            assert rel_err(wide, tiled) < tol
+    x1, x2 = rnd((600, 640), dev, 5), rnd((600, 640), dev, 6)
+    w, b = rnd((1280, 1280), dev, 7, 0.03), rnd((1280,), dev, 8)
+    pw = ops.pack_linear(w, b, dtype=dt)
+    tiled, wide = both(lambda: ops.linear(x1.to(dt), pw, x2=x2.to(dt)))
+    assert rel_err(tiled, wide) < tol
+    assert rel_err(wide, F.linear(torch.cat([qd(x1), qd(x2)], -1), qd(w), b)) < tol
+    for (bb, h, ww, cin, cout, stride, ups) in ((2, 17, 13, 256, 256, 1, False), (2, 8, 8, 128, 512, 1, True), (2, 16, 16, 64, 256, 2, False)):
+        xi = rnd((bb, cin, h, ww), dev, 9)
+        wt, bias, emb = rnd((cout, cin, 3, 3), dev, 10, (9 * cin) ** -0.5), rnd((cout,), dev, 11), rnd((bb, cout), dev, 12)
+        pc = ops.pack_conv3x3(wt, bias, dtype=dt)
+        xin = qd(xi).permute(0, 2, 3, 1).contiguous().to(dt)
+        tiled, wide = both(lambda: ops.conv3x3(xin, pc, stride=stride, upsample=ups, emb=emb))
+        assert rel_err(tiled, wide) < tol
+        xr = F.interpolate(qd(xi), scale_factor=2, mode="nearest") if ups else qd(xi)
+        ref = F.conv2d(xr, qd(wt), bias, stride=stride, padding=1) + emb[:, :, None, None]
+        assert rel_err(wide.permute(0, 3, 1, 2), ref) < tol
+    # the C entry point refuses the tile where it does not apply (fp32 output without split-K), ops falls back silently
+    x, w = rnd((300, 64), dev, 13), rnd((256, 64), dev, 14)
+    pw = ops.pack_linear(w, None, dtype=dt)
+    monkeypatch.setattr(ops, "FORCE_WIDE", 1)
+    out = ops.linear(x.to(dt), pw, out_dtype=torch.float32)
+    assert rel_err(out, F.linear(qd(x), qd(w))) < 1e-4
+    a = ops.hip.GemmArgs()
+    o16 = torch.empty(300, 256, dtype=dt, device=dev)
+    a.mode, a.A, a.lda, a.M, a.N, a.K, a.W, a.out, a.ld_out = 0, x.to(dt).data_ptr(), 64, 300, 256, 64, pw.w.data_ptr(), o16.data_ptr(), 256
+    a.dtype, a.alpha, a.tile_n, a.out_kind, a.batch, a.split_k = ops._dt(dt), 1.0, 256, 1, 1, 1
+    assert ops.hip.lib().sdmi_gemm_wide_applies(C.byref(a)) == 0
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) != 0
+
+
+def test_plan_takes_the_wide_tile_only_where_measured(dev):
+    ops = _ops()
+    assert ops._plan_gemm(4096, 3840, 1280, 160, True)[3] == 256          # level-2 qkv: 55 -> 43 us
+    assert ops._plan_gemm(131072, 512, 4608, 128, True)[3] == 256         # decoder 512-channel conv
+    assert ops._plan_gemm(4096, 1280, 11520, 160, True)[3] == 160         # 80 wide tiles: split-K on the small tile wins
+    assert ops._plan_gemm(65536, 1280, 320, 160, True)[3] == 160          # short K: not measured
+    assert ops._plan_gemm(4096, 3840, 1280, 160, False)[3] == 160
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,ups", [
     (2, 16, 16, 64, 128, 1, False), (1, 32, 32, 320, 320, 1, False), (2, 16, 16, 128, 128, 2, False),
     (2, 8, 8, 64, 64, 1, True), (2, 12, 20, 192, 96, 1, False), (1, 9, 7, 64, 32, 2, False),

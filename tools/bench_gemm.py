@@ -8,6 +8,7 @@ import torch
 from stablediffusion_amd import ops
 
 dev = torch.device("cuda:0")
+ops.FORCE_WIDE = int(os.environ.get("WIDE", "0"))      # 1 = the 256 x 256 x 32 tile where it applies
 ops.FORCE_ALGO = int(os.environ.get("ALGO", "0"))      # 1 = tiled kernel only, 2 = panel kernel (fails where it does not apply)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else None
@@ -60,6 +61,15 @@ for (kind, a), (tile, split, tile_m) in [(sh, c) for sh in SHAPES for c in confi
         pw = ops.pack_linear(torch.randn(n, k, device=dev) * 0.02, torch.randn(n, device=dev), tile_n=tn)
         res = torch.randn(m, n, device=dev).to(BF16) if kind == "lin" else None
         fn = lambda: ops.linear(x, pw, res=res)
+        if os.environ.get("ROTATE"):      # ROTATE=n: cycle through n input / residual sets (no cache-warm operands)
+            nrot = int(os.environ["ROTATE"])
+            xs = [torch.randn(m, k, device=dev).to(BF16) for _ in range(nrot)]
+            rs = [torch.randn(m, n, device=dev).to(BF16) if kind == "lin" else None for _ in range(nrot)]
+            cnt = [0]
+            def fn():
+                i = cnt[0] % nrot
+                cnt[0] += 1
+                return ops.linear(xs[i], pw, res=rs[i])
         flops = 2 * m * n * k
     try:
         for _ in range(3):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """UNet step time of the benchmark batch (development aid for same-box A/B runs with SDMI_LIB=<library>).
-usage: step_time.py [B=8] [iters=10]   -> ms per apply_model call, without and with the samplers' cfg_pairs hint"""
+usage: step_time.py [B=8] [iters=10]   -> ms per apply_model call, without and with the samplers' cfg_pairs hint
+env NO_WIDE=1: the GEMM plan without the 256 x 256 x 32 tile."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,12 +11,9 @@ import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda:0")
-if os.environ.get("PLAN_OLD"):          # A/B: the round-1 rule (short K, many tiles -> two-stage 128-row variant)
-    import math
-    from stablediffusion_amd import ops
-    new_plan = ops._plan_gemm
-    ops._plan_gemm = lambda m, n_w, k, tile_n=128: (128, 1, 2) if (k // 64 <= 10 and math.ceil(m / 128) * math.ceil(n_w / tile_n) >= 512) \
-        else new_plan(m, n_w, k, tile_n)
+from stablediffusion_amd import ops
+if os.environ.get("NO_WIDE"):           # A/B: never the 256 x 256 x 32 tile
+    ops.WIDE_TILE = False
 model = bench.build_model(dev, "eps", "fp16")
 z = torch.randn(B, 4, 64, 64, device=dev)
 x = torch.cat([z, z])
@@ -31,3 +29,13 @@ for kw in ({}, {"cfg_pairs": True}):
     e1.record()
     torch.cuda.synchronize()
     print(f"{os.environ.get('SDMI_LIB', 'default')} batch {2 * B} {kw}: {e0.elapsed_time(e1) / iters:.3f} ms", flush=True)
+if os.environ.get("DEC"):            # the first-stage decode of the same batch
+    for _ in range(2):
+        model.decode_first_stage(z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        model.decode_first_stage(z)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{os.environ.get('SDMI_LIB', 'default')} decode batch {B}: {e0.elapsed_time(e1) / iters:.3f} ms", flush=True)
