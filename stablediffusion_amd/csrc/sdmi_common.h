@@ -122,6 +122,29 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf_precise(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// The same GELU for the 16-bit epilogues, two values per instruction and no transcendental: erf(g / sqrt 2) = g Q(z) with
+// z = g^2 / 3.5^2 - 1 on |g| <= 3.5 sqrt 2 (clamped beyond: Q is scaled so that the clamp gives exactly +-1), Q a
+// degree-12 polynomial (Chebyshev fit, |erf error| <= 1e-6 evaluated in fp32; |GELU error| <= 2.3e-06 absolute - far
+// below the fp16 / bf16 rounding of the output).  20 VALU issues per PAIR (two v_med3, 16 v_pk_fma / v_pk_mul + the
+// gate product) against ~25 per value for the form above, whose rcp and exp run at quarter rate.
+__device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 g) {
+    constexpr float GC = 4.9497476f;
+    f32x2 gc;
+    gc[0] = __builtin_amdgcn_fmed3f(g[0], -GC, GC);
+    gc[1] = __builtin_amdgcn_fmed3f(g[1], -GC, GC);
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 z = __builtin_elementwise_fma(gc * gc, (f32x2){8.163265139e-02f, 8.163265139e-02f}, -one);
+    constexpr float c[13] = {2.855814369e-01f, -1.419164662e-01f, 1.037636884e-01f, -8.105812545e-02f, 6.256822945e-02f, -4.570597125e-02f, 3.155011345e-02f, -2.147688549e-02f, 1.265742458e-02f, -4.842874289e-03f, 2.575485832e-03f, -2.926710946e-03f, 1.261159998e-03f};
+    f32x2 q = {c[12], c[12]};
+#pragma unroll
+    for (int i = 11; i >= 0; --i) q = __builtin_elementwise_fma(q, z, (f32x2){c[i], c[i]});
+    const f32x2 hg = g * 0.5f;
+    return __builtin_elementwise_fma(hg * gc, q, hg);
+}
+__device__ __forceinline__ f32x4 gelu_erf_f4(const f32x4& g) {
+    const f32x2 lo = gelu_erf_pk((f32x2){g[0], g[1]}), hi = gelu_erf_pk((f32x2){g[2], g[3]});
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
 
 // ---- LDS-DMA issue (global_load_lds_dwordx4, 1 KiB per wave-instruction) ----
 // Issued through inline asm on purpose: with the builtin, hipcc orders every later ds_read behind the DMA

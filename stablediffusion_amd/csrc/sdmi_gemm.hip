@@ -49,8 +49,12 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
                 v += *reinterpret_cast<const f32x4*>(p.bias + wcol);
                 g += *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
             }
+            if (p.out_kind != 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= p.out_kind != 0 ? gelu_erf_precise(g[j]) : gelu_erf_f(g[j]);
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_precise(g[j]);
+            } else {
+                v *= gelu_erf_f4(g);
+            }
         } else if (p.bias != nullptr && !p.bias_per_row) {
             for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
         }

@@ -59,8 +59,12 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
     } else if (p.act == 2) {
+        if (p.out_kind != 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? gelu_erf_precise(v[j]) : gelu_erf_f(v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf_precise(v[j]);
+        } else {
+            v = gelu_erf_f4(v);
+        }
     }
     const bool full = (n + 3 < p.N);
     if (p.emb != nullptr) {
@@ -210,8 +214,7 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
             } else if (p.act == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
+                v = gelu_erf_f4(v);
             }
             if (p.emb != nullptr) v += eq[ni];
             if (p.res != nullptr) {
@@ -590,8 +593,12 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? silu_precise(v[j]) : silu_f(v[j]);
                 } else if (p.act == 2) {
+                    if (p.out_kind != 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = p.out_kind != 0 ? gelu_erf_precise(v[j]) : gelu_erf_f(v[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf_precise(v[j]);
+                    } else {
+                        v = gelu_erf_f4(v);
+                    }
                 }
                 if (p.emb != nullptr) v += eq[ni];
                 if (p.res != nullptr) {
@@ -638,8 +645,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
 #pragma unroll
                 for (int pi = 0; pi < TN / 2; ++pi) {
                     f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+                    v *= gelu_erf_f4(g);
                     ov[pi].x = elem_pack2<DT>(v[0], v[1]);
                     ov[pi].y = elem_pack2<DT>(v[2], v[3]);
                 }
@@ -659,8 +665,12 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 const int64_t n = (wcol >> 5) * 16 + (wcol & 15);
                 if (n >= p.N) continue;
                 f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
+                if (p.out_kind != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= p.out_kind != 0 ? gelu_erf_precise(g[j]) : gelu_erf_f(g[j]);
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_precise(g[j]);
+                } else {
+                    v *= gelu_erf_f4(g);
+                }
                 store_quad<DT>(p, m, n, v, zoff_out, zoff_res);
             }
         }

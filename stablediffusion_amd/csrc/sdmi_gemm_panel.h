@@ -64,8 +64,7 @@ __device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
             f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(g[j]);
+            v *= gelu_erf_f4(g);
             ov[pi].x = elem_pack2<DT>(v[0], v[1]);
             ov[pi].y = elem_pack2<DT>(v[2], v[3]);
         }

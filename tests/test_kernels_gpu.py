@@ -99,11 +99,16 @@ def test_geglu(dev):
     ref = a * F.gelu(gate)
     assert out.shape == (m, 4 * c)
     assert rel_err(out, ref) < 1e-4
-    # 16-bit output: the paired 16-byte store form of the epilogue (fast erf instead of erff: a rounding boundary may
-    # fall differently, nothing more)
+    # 16-bit output: the paired 16-byte store form of the epilogue with the packed polynomial erf (|erf error| <= 1e-6
+    # instead of erff): a rounding boundary may fall differently - by one ulp, in well under 1 % of the elements (the
+    # negative gates, where 1 + erf is small and the absolute error weighs more) - nothing more
     out16 = ops.linear(x.to(BF16), ops.pack_geglu(w, b))
     assert out16.dtype == BF16 and rel_err(out16.float(), out) < 5e-3
-    assert float((out16 != out.to(BF16)).float().mean()) < 1e-3
+    differ = out16 != out.to(BF16)
+    assert float(differ.float().mean()) < 1e-2
+    ulp = out.abs().clamp_min(1e-30).log2().floor().exp2() * 2.0 ** -7          # bf16: 8 significant bits
+    # (one ulp, plus the polynomial's ABSOLUTE GELU error of 2.4e-6 times the value branch where the gated product is tiny)
+    assert bool(((out16.float() - out).abs() <= 1.01 * ulp + 1e-5 * a.abs())[differ].all())
     # ... and with an output width that is not a multiple of 32 (falls back to the quad stores)
     w3, b3 = rnd((2 * 80, c), dev, 4, c ** -0.5), rnd((2 * 80,), dev, 5)
     a3, g3 = F.linear(q(x), q(w3), b3).chunk(2, dim=-1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """UNet step time of the benchmark batch (development aid for same-box A/B runs with SDMI_LIB=<library>).
 usage: step_time.py [B=8] [iters=10]   -> ms per apply_model call, without and with the samplers' cfg_pairs hint
-env NO_WIDE=1: the GEMM plan without the 256 x 256 x 32 tile."""
+env NO_WIDE=1: the GEMM plan without the 256 x 256 x 32 tile; GRAPH=1: hipGraph replay; DEC=1: also the decode."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,13 +19,17 @@ z = torch.randn(B, 4, 64, 64, device=dev)
 x = torch.cat([z, z])
 c = torch.randn(2 * B, 77, 1024, device=dev)
 ts = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+apply = model.apply_model
+if os.environ.get("GRAPH"):          # replay the step from a captured hipGraph (graph.py)
+    from stablediffusion_amd.graph import GraphedApplyModel
+    apply = GraphedApplyModel(model)
 for kw in ({}, {"cfg_pairs": True}):
     for _ in range(2):
-        model.apply_model(x, ts, c, **kw)
+        apply(x, ts, c, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        model.apply_model(x, ts, c, **kw)
+        apply(x, ts, c, **kw)
     e1.record()
     torch.cuda.synchronize()
     print(f"{os.environ.get('SDMI_LIB', 'default')} batch {2 * B} {kw}: {e0.elapsed_time(e1) / iters:.3f} ms", flush=True)
