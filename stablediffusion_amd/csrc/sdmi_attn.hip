@@ -51,6 +51,7 @@ __device__ const uint4 attn_zero16 = {0u, 0u, 0u, 0u};
 struct AttnArgs {
     const unsigned short* q; const unsigned short* k; const unsigned short* v; unsigned short* out;
     int heads, Nq, Nk;
+    int rowstore;      // out and ldo allow 16-byte row-coalesced stores
     int64_t ldq, ldk, ldv, ldo;
     float c;   // scale * log2(e)
 };
@@ -293,6 +294,36 @@ __global__ __launch_bounds__(256, SDMI_ATTN_OCC) void attn_fwd_d64_kernel(const 
     const float l_lane = (l_run[0] + l_run[1]) + (l_run1[0] + l_run1[1]);
     const float l_tot = l_lane + __shfl_xor(l_lane, 32);
     const float inv = 1.0f / l_tot;
+#ifndef SDMI_ATTN_ROWSTORE
+#define SDMI_ATTN_ROWSTORE 1      // A/B: 0 = every lane stores its own 8-byte pieces
+#endif
+    if (SDMI_ATTN_ROWSTORE && p.rowstore) {
+        // Row-coalesced store.  In the accumulator layout a lane holds sixteen 8-byte pieces of one output row, so a store
+        // instruction touches 32 rows (32 cache lines for 512 bytes) and a wave needs 16 of them.  The wave's 32 x 64 tile
+        // goes through LDS instead (its own 4.5 KiB of the K/V ring, which every wave has left behind the loop's last
+        // barrier; LDS operations of one wave execute in order, so no barrier is needed): 8 lanes then store one whole
+        // 128-byte row of the head - one cache line - and the wave issues 4 instructions of 8 lines each.  With 77 keys
+        // (cross-attention: two key tiles per launch) the stores were a third of the kernel's time.
+        unsigned char* ob = reinterpret_cast<unsigned char*>(lds) + wid * (32 * 144);      // row pitch 144 B
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w0, w1;
+            w0.x = elem_pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            w0.y = elem_pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            w1.x = elem_pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            w1.y = elem_pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(ob + lr * 144 + (8 * g + 4 * hf) * 2) = w0;
+            *reinterpret_cast<uint2*>(ob + lr * 144 + (32 + 8 * g + 4 * hf) * 2) = w1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(ob + row * 144 + ch * 16);
+            const int qr = qblk * QB + wid * 32 + row;
+            if (qr < p.Nq) *reinterpret_cast<uint4*>(Op + (int64_t)qr * p.ldo + ch * 8) = v;
+        }
+        return;
+    }
     if (qrow < p.Nq) {
         unsigned short* orow = Op + (int64_t)qrow * p.ldo;
 #pragma unroll
@@ -329,6 +360,7 @@ extern "C" int sdmi_attention_d64(const void* q, const void* k, const void* v, v
     a.heads = heads; a.Nq = Nq; a.Nk = Nk;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.c = scale * 1.4426950408889634f;
+    a.rowstore = (ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
     const dim3 grid((unsigned)((Nq + QB - 1) / QB), (unsigned)(nb * heads));
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SDMI_DTYPE_F16) hipLaunchKernelGGL(attn_fwd_d64_kernel<1>, grid, dim3(256), 0, hs, a);

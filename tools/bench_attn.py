@@ -7,7 +7,7 @@ from stablediffusion_amd import ops
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 LN2 = 0.6931471805599453
-for scale, (b, heads, nq, nk) in [(sc, shp) for sc in (0.125,) for shp in [(16, 5, 4096, 4096), (16, 10, 1024, 1024), (16, 20, 256, 256), (16, 5, 4096, 77), (16, 10, 1024, 77), (2, 5, 9216, 9216)]]:
+for scale, (b, heads, nq, nk) in [(sc, shp) for sc in (0.125,) for shp in [(16, 5, 4096, 4096), (16, 10, 1024, 1024), (16, 20, 256, 256), (16, 5, 4096, 77), (16, 10, 1024, 77), (16, 20, 256, 77), (2, 5, 9216, 9216)]]:
     c = heads * 64
     qkv = torch.randn(b * nq, 3 * c, device=dev)
     if scale == LN2:
