@@ -9,8 +9,8 @@ import collections, csv, json, sys
 
 
 def kernel_class(k):
-    if "sdmi_gemm_kernel<1" in k or "conv3x3_narrow_kernel" in k: return "conv"
-    if "sdmi_gemm_kernel<0" in k: return "linear_tiled"
+    if "sdmi_gemm_kernel<1" in k or "conv3x3_narrow_kernel" in k or "sdmi_gemm_wide_kernel<1" in k: return "conv"
+    if "sdmi_gemm_kernel<0" in k or "sdmi_gemm_wide_kernel<0" in k: return "linear_tiled"
     if "sdmi_gemm_panel_kernel" in k: return "linear_panel"
     if "splitk_reduce" in k: return "splitk_reduce"
     if "attn_fwd" in k: return "attention"
@@ -52,7 +52,7 @@ for r in csv.DictReader(open(sys.argv[3])):
         dur[f][0] += int(r["Calls"])
         dur[f][1] += float(r["TotalDurationNs"])
 res = {"note": "L2-miss bytes per launch from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
-               "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 --no-secondary` (end of round 2: LayerNorm fused at level 0, narrow conv kernel); FETCH_SIZE doubled "
+               "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 --no-secondary` (end of round 2, r02d: + 256 x 256 x 32 tile, hoisted residual loads, packed GELU, row-coalesced attention stores); FETCH_SIZE doubled "
                "per MI355X_MICROARCH.md; Infinity-Cache hits included (an upper bound on HBM bytes)",
        "unit_note": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); average "
                     "durations from the --kernel-trace --stats run of the same build",
