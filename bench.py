@@ -112,36 +112,108 @@ def cpu_baseline(model, h, ddim_steps, scale):
             "unet_step_s": t_step, "decode_s": t_dec}
 
 
-def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype):
-    """Per kernel family of ONE benchmark step (ddim_steps UNet forwards at batch 2B + one decode of B images):
-    algorithmic work (FLOPs for conv / linear / attention, bytes = one read + one write for GroupNorm / LayerNorm,
-    SURVEY.md §8(d)) / launch durations from HIP events recorded on the launch stream around every launch.
-    The top-level object is the family that takes the most GPU time; `families` carries all of them."""
+FAMILY_NAMES = {"conv3x3": "sdmi_gemm_kernel<1,...> (implicit-GEMM conv3x3, MFMA 16x16x32)",
+                "linear": "sdmi_gemm_kernel<0,...> (linear / conv1x1, MFMA 16x16x32)",
+                "attention": "attn_fwd_d64_kernel (flash attention d=64, MFMA 32x32x16)",
+                "groupnorm": "gn_stats_kernel + gn_apply_kernel (GroupNorm(32)+SiLU)", "layernorm": "layernorm_kernel"}
+
+
+def measured_peaks(dev):
+    """The box's own peaks (SURVEY.md section 8(d) asks for fractions against nominal AND measured peaks):
+    `mfma_tflops` = a register-only v_mfma_f32_16x16x32_f16 loop on pseudo-random operands on every CU (sdmi_probe_mfma:
+    no memory traffic, so it is the matrix rate at the clock the part holds on random data - the nominal 2.5 PFLOP/s
+    assumes 2.4 GHz), best of 4 launches of ~10 ms after a warm-up; `hbm_tbs` = a 16-byte-per-lane copy of 1 GiB
+    (sdmi_probe_copy), read + write bytes / time, best of 4."""
+    import ctypes as C
+    from stablediffusion_amd import hip
+    lib = hip.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.zeros(512, dtype=torch.float32, device=dev)
+    flop = C.c_double(0.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for i in range(5):
+        e0.record()
+        hip.check(lib.sdmi_probe_mfma(C.c_void_p(out.data_ptr()), 40000, C.byref(flop), stream), "sdmi_probe_mfma")
+        e1.record()
+        torch.cuda.synchronize()
+        if i:
+            best = max(best, flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    bw = 0.0
+    for i in range(5):
+        e0.record()
+        hip.check(lib.sdmi_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, stream), "sdmi_probe_copy")
+        e1.record()
+        torch.cuda.synchronize()
+        if i:
+            bw = max(bw, 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    del src, dst
+    return {"mfma_tflops": best, "hbm_tbs": bw,
+            "note": "mfma: register-only 16x16x32 f16 MFMA loop on pseudo-random operands, 256 workgroups x 8 waves "
+                    "(sdmi_probe_mfma); hbm: 1 GiB 16-byte-per-lane copy, read + write (sdmi_probe_copy); best of 4"}
+
+
+def collect_trace(fn):
+    """Run fn() with a HIP-event bracket around every traced launch -> [(kind, work, seconds, split_k, shape)]."""
     from stablediffusion_amd import ops
+    ops.TRACE = []
+    fn()
+    torch.cuda.synchronize()
+    tr, ops.TRACE = ops.TRACE, None
+    return [(k, f, e0.elapsed_time(e1) * 1e-3, sk, shp) for k, f, e0, e1, sk, shp in tr]
+
+
+def family_table(populations, peaks=None):
+    """populations: [(repeat, trace list)] - per kernel family: algorithmic work (FLOPs for conv / linear / attention,
+    bytes = one read + one write for GroupNorm / LayerNorm) / HIP-event launch durations."""
+    fam = {}
+    tot = {}
+    for kind in FAMILY_NAMES:
+        w = sum(rep * sum(f for k, f, _, _, _ in tr if k == kind) for rep, tr in populations)
+        tm = sum(rep * sum(t for k, _, t, _, _ in tr if k == kind) for rep, tr in populations)
+        n = sum(rep * sum(1 for k, _, _, _, _ in tr if k == kind) for rep, tr in populations)
+        if n:
+            tot[kind] = (w, tm, n)
+    t_all = sum(v[1] for v in tot.values())
+    for kind, (w, tm, n) in tot.items():
+        mfma = kind in ("conv3x3", "linear", "attention")
+        ach = w / tm / 1e12
+        peak = MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_TBS
+        fam[kind] = {"kernel": FAMILY_NAMES[kind], "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak,
+                     "unit": "TFLOP/s" if mfma else "TB/s", "frac": ach / peak, "work_per_launch": w / n,
+                     "avg_launch_us": tm / n * 1e6, "launches_per_step": n, "time_share": tm / t_all}
+        if peaks:
+            pm = peaks["mfma_tflops"] if mfma else peaks["hbm_tbs"]
+            fam[kind]["peak_measured"] = pm
+            fam[kind]["frac_measured"] = ach / pm if pm else None
+    return fam, t_all
+
+
+def executed_flops(tr):
+    return sum(f for k, f, _, _, _ in tr if k in ("conv3x3", "linear", "attention"))
+
+
+def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype, peaks, step_ms):
+    """Per kernel family of ONE benchmark step (ddim_steps UNet forwards at batch 2B + one decode of B images):
+    algorithmic work / launch durations from HIP events recorded on the launch stream around every launch.
+    The top-level object is the family that takes the most GPU time; `families` carries all of them."""
     dev = x_T.device
     c_in = torch.cat([uc, c]).contiguous()
     ts = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
     x_in = torch.cat([x_T, x_T])
+    unet = model.model.diffusion_model
+    temb = unet.time_embedding_table(torch.tensor([501]))[0]
 
-    def collect(fn):
-        ops.TRACE = []
-        fn()
-        torch.cuda.synchronize()
-        tr, ops.TRACE = ops.TRACE, None
-        return [(k, f, e0.elapsed_time(e1) * 1e-3, sk, shp) for k, f, e0, e1, sk, shp in tr]
-
-    # (cfg_pairs=True: the launch population of the timed DDIM loop, whose sampler passes the same hint)
-    collect(lambda: model.apply_model(x_in, ts, c_in, cfg_pairs=True))       # warm
-    un = collect(lambda: model.apply_model(x_in, ts, c_in, cfg_pairs=True))
-    de = collect(lambda: model.decode_first_stage(x_T))
-    out = {}
-    for kind in ("conv3x3", "linear", "attention", "groupnorm", "layernorm"):
-        u = [(f, t) for k, f, t, _, _ in un if k == kind]
-        d = [(f, t) for k, f, t, _, _ in de if k == kind]
-        fl = ddim_steps * sum(f for f, _ in u) + sum(f for f, _ in d)
-        tm = ddim_steps * sum(t for _, t in u) + sum(t for _, t in d)
-        n = ddim_steps * len(u) + len(d)
-        out[kind] = (fl, tm, n)
+    # (cfg_pairs=True + the hoisted time path: the launch population of the timed DDIM loop, whose sampler passes the
+    # same hints)
+    call = lambda: model.apply_model(x_in, ts, c_in, cfg_pairs=True, time_emb=temb)
+    collect_trace(call)       # warm
+    un = collect_trace(call)
+    de = collect_trace(lambda: model.decode_first_stage(x_T))
+    fam, t_all = family_table([(ddim_steps, un), (1, de)], peaks)
     if os.environ.get("SDMI_DUMP_SHAPES"):      # per-shape table of one UNet forward + one decode (development aid)
         agg = {}
         for src, lst in (("unet", un), ("dec", de)):
@@ -152,41 +224,113 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype):
             fh.write("src kind shape... splitk calls total_us T(FLOP|B)/s\n")
             for key, (n_, t_, f_) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 fh.write(" ".join(str(x) for x in key) + f" {n_} {t_ * 1e6:.1f} {f_ / t_ / 1e12:.2f}\n")
-    names = {"conv3x3": "sdmi_gemm_kernel<1,...> (implicit-GEMM conv3x3, MFMA 16x16x32)",
-             "linear": "sdmi_gemm_kernel<0,...> (linear / conv1x1, MFMA 16x16x32)",
-             "attention": "attn_fwd_d64_kernel (flash attention d=64, MFMA 32x32x16)",
-             "groupnorm": "gn_stats_kernel + gn_apply_kernel (GroupNorm(32)+SiLU)", "layernorm": "layernorm_kernel"}
-    t_all = sum(v[1] for v in out.values())
-    fam = {}
-    for kind, (w, tm, n) in out.items():
-        if n == 0:
-            continue
-        mfma = kind in ("conv3x3", "linear", "attention")
-        ach = w / tm / 1e12
-        fam[kind] = {"kernel": names[kind], "bound": "mfma" if mfma else "hbm", "achieved": ach,
-                     "peak": MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_TBS, "unit": "TFLOP/s" if mfma else "TB/s",
-                     "frac": ach / (MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_TBS), "work_per_launch": w / n,
-                     "avg_launch_us": tm / n * 1e6, "launches_per_step": n, "time_share": tm / t_all}
     dom = max(fam, key=lambda k: fam[k]["time_share"])
     # HBM-side bytes per launch of each family: PMC figures of separate rocprofv3 passes over this same command,
     # committed under profiles/ (counters cannot be read from inside the process); null when the file is absent
-    traffic, tnote = None, "no profiles/r02_traffic.json"
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            tj = json.load(fh)
-        for kind in fam:
-            e = tj.get("per_family", {}).get(kind)
-            if e:
-                fam[kind]["traffic"] = e["bytes_per_launch"]
-        traffic = fam[dom].get("traffic")
-        tnote = tj.get("note", "")
+    traffic, tnote = None, "no profiles/r0?_traffic.json"
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            for kind in fam:
+                e = tj.get("per_family", {}).get(kind)
+                if e:
+                    fam[kind]["traffic"] = e["bytes_per_launch"]
+            traffic = fam[dom].get("traffic")
+            tnote = f"profiles/{name}: " + tj.get("note", "")
+            break
     top = dict(fam[dom])
     top.update({"traffic": traffic, "traffic_note": tnote, "dtype": dtype, "families": fam,
+                "peaks_measured": peaks,
+                "bracket_sum_ms_per_step": t_all * 1e3, "step_ms": step_ms,
                 "note": "time-dominant kernel family of the step; durations are HIP-event brackets around each launch "
-                        "(split-K reduce launches and the event-to-event gap included); mfma fractions against the "
-                        "2.5 PFLOP/s dense 16-bit peak, hbm fractions against the 8 TB/s spec"})
-    return top
+                        "(split-K reduce launches and the event-to-event gap included, so the brackets of a step add up "
+                        "to MORE than the step takes - bracket_sum_ms_per_step vs step_ms: fractions are conservative, "
+                        "time_share is relative to the bracket sum); frac = against the nominal 2.5 PFLOP/s dense 16-bit "
+                        "peak / the 8 TB/s HBM spec, frac_measured = against peaks_measured (this box, this run)"})
+    return top, executed_flops(un), executed_flops(de)
+
+
+def leg_768(model, dev, args, peaks):
+    """BASELINE.json configs[3]: SD2.1-v 768^2 - v-prediction, 96x96 latent (9216-token self-attention), 50 DDIM steps
+    + CFG, batch 8 on one GPU; one timed sampling + decode after one warm-up, and the per-family table of its launches."""
+    from stablediffusion_amd.ddim import DDIMSampler
+    from stablediffusion_amd import ops
+    B, h = 8, 96
+    prev = model.parameterization
+    model.parameterization = "v"
+    try:
+        x_T = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(77)).to(dev)
+        c = torch.randn(B, 77, 1024, generator=torch.Generator().manual_seed(4321)).to(dev)
+        uc = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(99)).expand(B, -1, -1).contiguous().to(dev)
+        sampler = DDIMSampler(model)
+
+        def one():
+            smp, _ = sampler.sample(S=args.ddim_steps, batch_size=B, shape=[4, h, h], conditioning=c, verbose=False,
+                                    unconditional_guidance_scale=args.scale, unconditional_conditioning=uc, eta=0.0, x_T=x_T)
+            return ops.image_to_u8(model.decode_first_stage(smp))
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert img.shape == (B, 8 * h, 8 * h, 3)
+        c_in = torch.cat([uc, c]).contiguous()
+        ts = torch.full((2 * B,), 501, device=dev, dtype=torch.long)
+        x_in = torch.cat([x_T, x_T])
+        temb = model.model.diffusion_model.time_embedding_table(torch.tensor([501]))[0]
+        call = lambda: model.apply_model(x_in, ts, c_in, cfg_pairs=True, time_emb=temb)
+        call()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(3):
+            call()
+        e1.record()
+        model.decode_first_stage(x_T)
+        e2.record()
+        torch.cuda.synchronize()
+        step_ms, dec_ms = e0.elapsed_time(e1) / 3, e1.elapsed_time(e2)
+        un = collect_trace(call)
+        de = collect_trace(lambda: model.decode_first_stage(x_T))
+        fam, _ = family_table([(args.ddim_steps, un), (1, de)], peaks)
+    finally:
+        model.parameterization = prev
+    alg = (2 * args.ddim_steps * UNET_GFLOP[h] + DEC_GFLOP[h]) * 1e9 * B
+    exe = args.ddim_steps * executed_flops(un) + executed_flops(de)
+    return {"workload": f"BASELINE.json configs[3]: SD2.1-v 768^2 (96x96 latent, 9216-token self-attention), v-prediction, "
+                        f"batch {B}, {args.ddim_steps} DDIM steps + CFG (UNet batch {2 * B}), decode + uint8",
+            "batch": B, "s_per_batch": dt, "images_per_sec": B / dt,
+            "unet_step_ms_cfg_pairs": step_ms, "decode_ms": dec_ms,
+            "unet_step_tflops_algorithmic": 2 * B * UNET_GFLOP[h] / step_ms,      # GFLOP / ms = TFLOP/s
+            "unet_step_mfma_frac": 2 * B * UNET_GFLOP[h] / step_ms / MFMA_PEAK_TFLOPS,
+            "tflops_algorithmic_unhoisted": alg / dt / 1e12, "tflops_executed": exe / dt / 1e12,
+            "mfma_frac_end_to_end_executed": exe / dt / 1e12 / MFMA_PEAK_TFLOPS,
+            "mfma_frac_measured_end_to_end_executed": exe / dt / 1e12 / peaks["mfma_tflops"] if peaks else None,
+            "families": fam}
+
+
+def leg_decode_768(model, dev, peaks):
+    """BASELINE.json configs[4]: AutoencoderKL decode_first_stage standalone at 768^2, batch 16 (92.1 TFLOP)."""
+    B, h = 16, 96
+    z = torch.randn(B, 4, h, h, generator=torch.Generator().manual_seed(5)).to(dev)
+    model.decode_first_stage(z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        img = model.decode_first_stage(z)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    assert img.shape == (B, 3, 8 * h, 8 * h)
+    de = collect_trace(lambda: model.decode_first_stage(z))
+    fam, _ = family_table([(1, de)], peaks)
+    tf = B * DEC_GFLOP[h] / ms
+    return {"workload": "BASELINE.json configs[4]: AutoencoderKL decode_first_stage standalone, 768^2, batch 16",
+            "batch": B, "decode_ms": ms, "images_per_sec": B / (ms * 1e-3), "tflops_algorithmic": tf,
+            "mfma_frac": tf / MFMA_PEAK_TFLOPS, "mfma_frac_measured": tf / peaks["mfma_tflops"] if peaks else None,
+            "tflops_executed": executed_flops(de) / (ms * 1e-3) / 1e12, "families": fam}
 
 
 def secondary_dtype(model, dt, x_in, ts, c_in, x_T, ddim_steps, B):
@@ -238,6 +382,8 @@ def main():
                     help="MFMA operand / storage type (the reference's use_fp16 / use_bf16 policy).  fp16 is the headline: "
                          "it is what v2-inference.yaml ships and it meets the 1e-2 parity gate; bf16 runs at the same rate")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary-dtype (bf16) UNet-step / decode timing")
+    ap.add_argument("--no-legs", action="store_true", help="skip the BASELINE configs[3] (768^2 v-prediction) and configs[4] "
+                                                          "(standalone 768^2 batch-16 decode) legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -304,10 +450,15 @@ def main():
                                f"{args.ddim_steps} DDIM steps + CFG (UNet batch {2 * B}), decode + uint8; "
                                f"BASELINE.json configs[{1 if B == 1 else 2}]",
                    "global_batch": world * B, "latent": h, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world}",
-                   "parameterization": args.parameterization, "hip_graph": use_graph, "cfg_pairs": True},
+                   "parameterization": args.parameterization, "hip_graph": use_graph, "cfg_pairs": True,
+                   "time_path_hoisted": True},
         "unet_step_ms": None,
-        "effective_tflops_per_gpu": value / world * flop_per_image / 1e12 if flop_per_image else None,
-        "mfma_frac_end_to_end": value / world * flop_per_image / 1e12 / MFMA_PEAK_TFLOPS if flop_per_image else None,
+        # work / time of the timed region.  `algorithmic_unhoisted`: the reference's own FLOP count (SURVEY.md section 8(d):
+        # 2 x ddim_steps x 804.3 + 2514.5 GFLOP per 512^2 image) over the measured time - an equivalent-work rate, NOT what
+        # the matrix pipes executed, because three hoists remove work from the step loop; `effective_tflops_per_gpu` /
+        # `mfma_frac_end_to_end` (filled in below from the launch trace) count only the launches that ran.
+        "algorithmic_tflops_per_gpu_unhoisted": value / world * flop_per_image / 1e12 if flop_per_image else None,
+        "effective_tflops_per_gpu": None, "mfma_frac_end_to_end": None,
     }
     # UNet step ms (one CFG-batched forward), HIP events on the launch stream
     c_in = torch.cat([uc, c]).contiguous()
@@ -321,12 +472,14 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     result["unet_step_ms"] = e0.elapsed_time(e1) / 5
-    # the same CFG batch with the samplers' cfg_pairs hint (rows b and b + B are the same latent and step: the layers in
-    # front of the first cross-attention run once per pair) - what the timed DDIM loop above calls
-    model.apply_model(x_in, ts, c_in, cfg_pairs=True)
+    # the same CFG batch with the samplers' hints: cfg_pairs (rows b and b + B are the same latent and step: the layers in
+    # front of the first cross-attention run once per pair) and the hoisted time path (a row of the per-schedule
+    # table instead of four launches) - what the timed DDIM loop above calls
+    temb = model.model.diffusion_model.time_embedding_table(torch.tensor([501]))[0]
+    model.apply_model(x_in, ts, c_in, cfg_pairs=True, time_emb=temb)
     e0.record()
     for _ in range(5):
-        model.apply_model(x_in, ts, c_in, cfg_pairs=True)
+        model.apply_model(x_in, ts, c_in, cfg_pairs=True, time_emb=temb)
     e1.record()
     torch.cuda.synchronize()
     result["unet_step_ms_cfg_pairs"] = e0.elapsed_time(e1) / 5
@@ -355,22 +508,61 @@ def main():
         t_img = time.perf_counter() - t1
         cin1 = torch.cat([uc1, c1]).contiguous()
         xin1, ts1 = torch.cat([x1, x1]), torch.full((2,), 501, device=dev, dtype=torch.long)
+        temb1 = model.model.diffusion_model.time_embedding_table(torch.tensor([501]))[0]
+        hints = dict(cfg_pairs=True, time_emb=temb1)        # what the samplers pass (guidance pairs, hoisted time path)
         steps_ms = {}
-        for name, fn in (("graph", GraphedApplyModel(model)), ("eager", model.apply_model)):
-            fn(xin1, ts1, cin1)
+        for name, fn, kw in (("graph", GraphedApplyModel(model), hints), ("eager", model.apply_model, hints),
+                             ("graph_plain", GraphedApplyModel(model), {}), ("eager_plain", model.apply_model, {})):
+            fn(xin1, ts1, cin1, **kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(10):
-                fn(xin1, ts1, cin1)
+                fn(xin1, ts1, cin1, **kw)
             torch.cuda.synchronize()
             steps_ms[name] = (time.perf_counter() - t1) / 10 * 1e3
+        b1_un = collect_trace(lambda: model.apply_model(xin1, ts1, cin1, **hints))
+        b1_de = collect_trace(lambda: model.decode_first_stage(x1))
+        b1_fam, b1_sum = family_table([(args.ddim_steps, b1_un), (1, b1_de)])
+        b1_dom = max(b1_fam, key=lambda k: b1_fam[k]["time_share"])
+        b1_roof = dict(b1_fam[b1_dom])
+        b1_roof.update({"families": b1_fam, "bracket_sum_ms_per_image": b1_sum * 1e3,
+                        "launches_per_unet_step": len(b1_un),
+                        "note": "as the top-level roofline object, for the batch-1 launch population (HIP-event brackets: "
+                                "at this batch most launches are shorter than the bracket's own event-to-event gap, so "
+                                "the fractions are lower bounds)"})
         result["batch1"] = {"workload": "BASELINE.json configs[1]: batch 1, UNet batch 2 (CFG), hipGraph replay of the UNet step",
                             "s_per_image": t_img, "images_per_sec": 1.0 / t_img,
-                            "unet_step_ms_graph": steps_ms["graph"], "unet_step_ms_eager": steps_ms["eager"]}
+                            "unet_step_ms_graph": steps_ms["graph"], "unet_step_ms_eager": steps_ms["eager"],
+                            "unet_step_ms_graph_no_hints": steps_ms["graph_plain"],
+                            "unet_step_ms_eager_no_hints": steps_ms["eager_plain"],
+                            "unet_step_tflops_algorithmic": 2 * UNET_GFLOP.get(h, 0) / steps_ms["graph"],
+                            "unet_step_mfma_frac": 2 * UNET_GFLOP.get(h, 0) / steps_ms["graph"] / MFMA_PEAK_TFLOPS,
+                            "roofline": b1_roof,
+                            "note": "unet_step_ms_graph / _eager: with the samplers' hints (cfg_pairs, hoisted time path) - what "
+                                    "s_per_image runs; *_no_hints: plain apply_model(x, t, c)"}
 
     if rank == 0:
+        peaks = measured_peaks(dev)
+        result["peaks_measured"] = peaks
         if not args.no_roofline:
-            result["roofline"] = roofline(model, sampler, B, h, args.ddim_steps, c, uc, x_T, args.dtype)
+            result["roofline"], ex_unet, ex_dec = roofline(model, sampler, B, h, args.ddim_steps, c, uc, x_T, args.dtype, peaks,
+                                                           dt / args.steps * 1e3)
+            exe = args.ddim_steps * ex_unet + ex_dec            # FLOPs of the launches of ONE bench step on this rank
+            alg = flop_per_image * B
+            result["effective_tflops_per_gpu"] = exe / (dt / args.steps) / 1e12
+            result["mfma_frac_end_to_end"] = exe / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS
+            result["mfma_frac_measured_end_to_end"] = exe / (dt / args.steps) / 1e12 / peaks["mfma_tflops"]
+            result["hoists"] = {
+                "executed_gflop_per_step": exe / 1e9, "algorithmic_gflop_per_step_unhoisted": alg / 1e9,
+                "removed_gflop_per_step": (alg - exe) / 1e9,
+                "what": "work the step loop does not execute: (i) cross-attention K/V = to_k/to_v(context) of all 16 blocks, "
+                        "computed once per prompt (attention.py:312-313); (ii) the timestep path (sinusoid, time MLP, 22 "
+                        "embedding projections) computed once per schedule for all steps (openai_model.py:956-964, 280); "
+                        "(iii) the guidance-pair prefix: conv_in, the first ResBlock, GroupNorm + proj_in and the first "
+                        "self-attention run once per (uncond, cond) pair (UNetModel._forward_cfg_pairs)"}
+        if world == 1 and h == 64 and not args.no_legs:
+            result["config3_768_v"] = leg_768(model, dev, args, peaks)
+            result["config4_decode_768_b16"] = leg_decode_768(model, dev, peaks)
         if world == 1 and not args.no_secondary:
             result["secondary_dtype"] = secondary_dtype(model, "bf16" if args.dtype == "fp16" else "fp16", x_in, ts, c_in, x_T,
                                                         args.ddim_steps, B)

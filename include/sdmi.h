@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 11: + sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -187,9 +187,10 @@ int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw);
  * through PyTorch): same arguments, kernels and results as sdmi_groupnorm, but the per-slab statistics live in a
  * static device array inside the library (SDMI_GROUPNORM_NOALLOC_MAX_BYTES per GPU, held until the process ends)
  * instead of caller memory; no hipMalloc / hipFree / allocating routine is called.
- *   - limit: sdmi_groupnorm_workspace_bytes(nb, hw) <= SDMI_GROUPNORM_NOALLOC_MAX_BYTES, i.e. nb * slabs(hw) <= 4096
- *     (slabs(hw) = 1 up to 1024 pixels, else ceil(hw / max(64, ceil(hw / 256))) <= 256: e.g. 16 images of any size);
- *     beyond it the call returns SDMI_ERR_TOO_LARGE and launches nothing.
+ *   - limit: nb * slabs(hw) <= 4096 slab entries (SDMI_GROUPNORM_NOALLOC_MAX_BYTES / 384), where slabs(hw) is what the
+ *     launch really uses: 1 up to 1024 pixels (the fused single launch), else ceil(hw / max(64, ceil(hw / 256))) <= 256
+ *     - e.g. 16 images of any size, 4096 images of 32 x 32; beyond it the call returns SDMI_ERR_TOO_LARGE and
+ *     launches nothing.  (sdmi_groupnorm_workspace_bytes() is an upper bound of the same count, not the limit.)
  *   - the array's device address is looked up on the first call made with a device current (hipGetSymbolAddress, once
  *     per device, per-device pointer kept): make one call outside any stream capture first.
  *   - every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams) race - serialise them.
@@ -211,6 +212,7 @@ int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* o
  * the head split/merge rearranges); never materialises the [B*H, Nq, Nk] score tensor.
  * q rows are [nb*Nq, ldq] with head h at columns [h*64, h*64+64); likewise k, v ([nb*Nk, ld*]) and
  * out.  All leading dimensions multiples of 8.  Nq, Nk arbitrary (>0).
+ * Limit: nb * heads <= 65535 (one grid.y slot per (image, head)); SDMI_ERR_BAD_ARG beyond it - split the batch.
  * ---------------------------------------------------------------------------------------- */
 int sdmi_attention_d64(const void* q, const void* k, const void* v, void* out,
                        int32_t nb, int32_t heads, int32_t Nq, int32_t Nk,
@@ -325,6 +327,19 @@ int sdmi_diag_gaussian(const float* parameters, float* mean, float* log_var, flo
 int sdmi_mul_add(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 
 int sdmi_image_to_u8(const float* x, uint8_t* out, int32_t nb, int32_t C, int64_t hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aids (no counterpart in the reference; they compute nothing the path uses).  bench.py times them with
+ * HIP events to state roofline fractions against the MEASURED peaks of the box it runs on as well as the nominal ones
+ * (SURVEY.md section 8(d)).
+ *   sdmi_probe_mfma: a register-only v_mfma_f32_16x16x32_f16 loop on pseudo-random operands, 256 workgroups x 8 waves,
+ *       `iters` x 16 MFMAs per wave; *flop (host pointer, may be NULL) receives the FLOP count of the launch.  `out`:
+ *       2 KiB of device memory (never written in practice).
+ *   sdmi_probe_copy: dst[0, bytes) = src[0, bytes) by 16-byte lanes (bytes % 16 == 0, 16-byte aligned pointers): the
+ *       streaming HBM rate is 2 * bytes / time.
+ * ---------------------------------------------------------------------------------------- */
+int sdmi_probe_mfma(float* out, int32_t iters, double* flop, void* stream);
+int sdmi_probe_copy(const void* src, void* dst, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -192,7 +192,11 @@ __global__ __launch_bounds__(256, 1) void vae_attn_kernel(const VaeAttnArgs p) {
         } else {
             if (MODE == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -my_m)) * my_il;
+                // The exponent is clamped at 0 (for a real column it is <= 0 already: m is the row maximum).  In a ragged
+                // last tile the columns past N have zero logits, so their exponent is -m: without the clamp a row whose real
+                // logits are all strongly negative would give them the weight exp2(-m) / l = inf, and inf * 0 (their V rows
+                // are zero) = NaN for the whole output row.  Clamped, the weight is at most 1 / l and the product is 0.
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], p.c, -my_m), 0.f)) * my_il;
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -255,13 +259,11 @@ __global__ __launch_bounds__(256, 1) void vae_attn_kernel(const VaeAttnArgs p) {
 template <int DT, int D>
 int launch_vae(const VaeAttnArgs& qk, const VaeAttnArgs& ap, int mode, dim3 grid, hipStream_t s) {
     constexpr size_t lds = 2 * (2 * (size_t)CT * D * 2 + 4096);
-    static std::once_flag once;          // one per instantiation
-    static int attr_status = SDMI_OK;
-    std::call_once(once, [] {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_kernel<DT, D, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_kernel<DT, D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_kernel<DT, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            attr_status = SDMI_ERR_LAUNCH;
+    static SdmiPerDeviceOnce once;       // one per instantiation, run once per device
+    const int attr_status = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_kernel<DT, D, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_kernel<DT, D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(vae_attn_kernel<DT, D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     });
     if (attr_status != SDMI_OK) return attr_status;
     hipLaunchKernelGGL((vae_attn_kernel<DT, D, 0>), grid, dim3(256), lds, s, qk);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/sdmi.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -14,6 +15,22 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return SDMI_ERR_LAUNCH; \
     } while (0)
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a function, so "once" means once per device: a process
+// that drives several GPUs runs `set` on each of them the first time it launches there.  Thread-safe; a refusal
+// sticks and is reported on every later call (SDMI_ERR_LAUNCH).
+struct SdmiPerDeviceOnce {
+    static constexpr int MAX_DEVICES = 64;
+    std::mutex m;
+    signed char state[MAX_DEVICES] = {};      // 0 = not run yet, 1 = done, -1 = refused
+    template <class F> int run(F&& set) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return SDMI_ERR_LAUNCH;
+        std::lock_guard<std::mutex> lock(m);
+        if (state[dev] == 0) state[dev] = set() ? 1 : -1;
+        return state[dev] > 0 ? SDMI_OK : SDMI_ERR_LAUNCH;
+    }
+};
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned)b) << 16);

@@ -162,15 +162,15 @@ int sdmi_conv_narrow_launch(const sdmi_gemm_args& p, hipStream_t s) {
     if (p.H != p.Ho || p.W_in != p.Wo || p.M >= (1LL << 31)) return 0;
     if (p.out_kind == 0 && (p.ld_out % 4 != 0)) return 0;
     if ((((uintptr_t)p.A | (uintptr_t)p.W) & 15) != 0) return 0;
-    static std::once_flag once;
-    static int attr_status = SDMI_OK;
-    std::call_once(once, [] {
+    static SdmiPerDeviceOnce once;      // per device: hipFuncSetAttribute acts on the current device
+    const int attr_status = once.run([] {
         const kern_t all[6] = {conv3x3_narrow_kernel<0, 4>, conv3x3_narrow_kernel<0, 10>, conv3x3_narrow_kernel<0, 0>,
                                conv3x3_narrow_kernel<1, 4>, conv3x3_narrow_kernel<1, 10>, conv3x3_narrow_kernel<1, 0>};
+        bool ok = true;
         for (int i = 0; i < 6; ++i)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(all[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    9 * (NARROW_MAX_CIN / 32) * 1024) != hipSuccess)
-                attr_status = SDMI_ERR_LAUNCH;
+            ok = (hipFuncSetAttribute(reinterpret_cast<const void*>(all[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      9 * (NARROW_MAX_CIN / 32) * 1024) == hipSuccess) && ok;
+        return ok;
     });
     if (attr_status != SDMI_OK) return attr_status;
     const int cs = p.Cin / 32;

@@ -202,15 +202,14 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         return SDMI_ERR_BAD_ARG;      // (the tiled kernel never holds a whole row)
     }
     if (p.ln_gamma != nullptr) return SDMI_ERR_BAD_ARG;
-    // dynamic-LDS attribute of every instantiation, once per process (thread-safe; a refusal is reported, not ignored)
-    static std::once_flag attr_once;
-    static int attr_status = SDMI_OK;
-    std::call_once(attr_once, [] {
+    // dynamic-LDS attribute of every instantiation, once per DEVICE (SdmiPerDeviceOnce)
+    static SdmiPerDeviceOnce attr_once;
+    const int attr_status = attr_once.run([] {
         int (*const fns[4])() = {sdmi_gemm_unit_attrs_m0_bf16, sdmi_gemm_unit_attrs_m0_f16, sdmi_gemm_unit_attrs_m1_bf16,
                                  sdmi_gemm_unit_attrs_m1_f16};
-        for (int i = 0; i < 4; ++i)
-            if (fns[i]() != SDMI_OK) attr_status = SDMI_ERR_LAUNCH;
-        if (sdmi_gemm_wide_attrs_bf16() != SDMI_OK || sdmi_gemm_wide_attrs_f16() != SDMI_OK) attr_status = SDMI_ERR_LAUNCH;
+        bool ok = true;
+        for (int i = 0; i < 4; ++i) ok = (fns[i]() == SDMI_OK) && ok;
+        return (sdmi_gemm_wide_attrs_bf16() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16() == SDMI_OK) && ok;
     });
     if (attr_status != SDMI_OK) return attr_status;
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(split > 1 ? split : batch));

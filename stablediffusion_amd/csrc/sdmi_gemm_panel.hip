@@ -53,14 +53,14 @@ int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s) {
 #define SDMI_PANEL_L_MIN_N 960
 #endif
     const int which = p.geglu ? 2 : (n_w >= SDMI_PANEL_L_MIN_N ? 1 : 0);
-    static std::once_flag once;
-    static int attr_status = SDMI_OK;
-    std::call_once(once, [] {
+    static SdmiPerDeviceOnce once;      // per device: hipFuncSetAttribute acts on the current device
+    const int attr_status = once.run([] {
+        bool ok = true;
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 3; ++b)
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k320[a][b].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        k320[a][b].lds) != hipSuccess)
-                    attr_status = SDMI_ERR_LAUNCH;
+                ok = (hipFuncSetAttribute(reinterpret_cast<const void*>(k320[a][b].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          k320[a][b].lds) == hipSuccess) && ok;
+        return ok;
     });
     if (attr_status != SDMI_OK) return attr_status;
     const PanelVariant& v = k320[p.dtype == SDMI_DTYPE_F16 ? 1 : 0][which];

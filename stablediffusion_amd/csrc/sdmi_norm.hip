@@ -167,7 +167,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
         }
     }
     __syncthreads();
-    // per-group totals: GN_THREADS/Gw threads per group each sum a fixed interleaved subset, then one thread adds them
+    // per-group totals: GN_THREADS/Gw threads per group each sum a fixed interleaved subset; the partials of one group
+    // sit Gw lanes apart, so a butterfly over the lane offsets Gw, 2Gw, ... < 64 adds those of a wave (Gw is a power of
+    // two <= 32), and one thread per group adds the four wave totals - a fixed order, bit-reproducible from call to call.
+    // (A single thread walking all GN_THREADS/Gw partials cost 7 us of the 10 us an 8 x 8 x 1280 launch took.)
     const int nparts = GN_THREADS / Gw;
     {
         const int g = tid % Gw, part = tid / Gw;
@@ -178,13 +181,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
             S += rowp[g * cpg + j];
             SS += rowp[Cw + g * cpg + j];
         }
-        part_sum[part * Gw + g][0] = S;
-        part_sum[part * Gw + g][1] = SS;
+        for (int off = Gw; off < 64; off <<= 1) {
+            S += __shfl_xor(S, off);
+            SS += __shfl_xor(SS, off);
+        }
+        if ((tid & 63) < Gw) {
+            part_sum[(tid >> 6) * Gw + g][0] = S;
+            part_sum[(tid >> 6) * Gw + g][1] = SS;
+        }
     }
     __syncthreads();
     if (tid < Gw) {
         float S = 0.f, SS = 0.f;
-        for (int part = 0; part < nparts; ++part) { S += part_sum[part * Gw + tid][0]; SS += part_sum[part * Gw + tid][1]; }
+        for (int w = 0; w < GN_THREADS / 64; ++w) { S += part_sum[w * Gw + tid][0]; SS += part_sum[w * Gw + tid][1]; }
         const float n = (float)((p_end - p_begin) * cpg);
         const float mean = S / n;
         float m2 = SS - S * mean;
@@ -331,6 +340,16 @@ extern "C" int64_t sdmi_groupnorm_workspace_bytes(int32_t nb, int64_t hw) {
     return (int64_t)nb * nslab * GN_GROUPS * 3 * (int64_t)sizeof(float);
 }
 
+#ifndef SDMI_GN_FUSED_MAX_HW
+#define SDMI_GN_FUSED_MAX_HW 1024
+#endif
+// Slabs per image groupnorm_launch really uses: one (the fused single launch) up to SDMI_GN_FUSED_MAX_HW pixels.
+static int64_t gn_launch_slabs(int64_t hw) {
+    if (hw <= SDMI_GN_FUSED_MAX_HW) return 1;
+    const int64_t P = gn_slab_pixels(hw);
+    return (hw + P - 1) / P;
+}
+
 // Argument checks shared by the two GroupNorm entry points (everything except the scratch buffer).
 static int groupnorm_check(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma, const float* beta,
                            const void* out, int32_t nb, int64_t hw, int32_t dtype) {
@@ -351,12 +370,9 @@ static int groupnorm_launch(const void* x1, const void* x2, int32_t C1, int32_t 
                             void* stream) {
     const int C = C1 + C2;
     // Small images (<= 1024 pixels): one slab per image and one fused launch; else P-pixel slabs and two launches.
-#ifndef SDMI_GN_FUSED_MAX_HW
-#define SDMI_GN_FUSED_MAX_HW 1024
-#endif
     const bool fused = hw <= SDMI_GN_FUSED_MAX_HW;
     const int64_t P = fused ? hw : gn_slab_pixels(hw);
-    const int nslab = (int)((hw + P - 1) / P);
+    const int nslab = (int)gn_launch_slabs(hw);
     // channel chunks (whole groups, 16-byte aligned) until the grid can fill the chip
     int gch = 1;
     while (gch < GN_GROUPS && (int64_t)nslab * nb * gch < 512 && (C / (gch * 2)) % 8 == 0) gch *= 2;
@@ -419,7 +435,8 @@ extern "C" int sdmi_groupnorm_noalloc(const void* x1, const void* x2, int32_t C1
                                       int32_t dtype, void* stream) {
     const int st = groupnorm_check(x1, x2, C1, C2, gamma, beta, out, nb, hw, dtype);
     if (st != SDMI_OK) return st;
-    if (sdmi_groupnorm_workspace_bytes(nb, hw) > SDMI_GROUPNORM_NOALLOC_MAX_BYTES) return SDMI_ERR_TOO_LARGE;
+    // the limit counts the slab entries the launch really writes (one per image for the fused small-image form)
+    if ((int64_t)nb * gn_launch_slabs(hw) > GN_NOALLOC_MAX_SLABS) return SDMI_ERR_TOO_LARGE;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEVICES) return SDMI_ERR_LAUNCH;
     float* ptr;

@@ -15,7 +15,7 @@ from .schedule import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
 class DDIMSampler(object):
-    def __init__(self, model, schedule="linear", device=None, hip_graph=False, cfg_pairs=True, **kwargs):
+    def __init__(self, model, schedule="linear", device=None, hip_graph=False, cfg_pairs=True, hoist_time=True, **kwargs):
         """hip_graph=True replays the UNet step from a captured hipGraph (graph.py): worth it when the step is
         launch-bound (small batch); results are bit-identical to eager launches.
         cfg_pairs=True tells the UNet that a guidance batch is cat([x, x]) (it is: this sampler builds it), so that the
@@ -24,6 +24,10 @@ class DDIMSampler(object):
         super().__init__()
         self.model = model
         self.cfg_pairs = cfg_pairs
+        # hoist_time=True: the UNet's whole timestep path (sinusoid, time MLP, the 22 ResBlock projections) is computed for
+        # all S steps of the schedule at once in make_schedule and handed to the UNet row by row
+        self.hoist_time = hoist_time
+        self._time_table = None
         self._apply = model.apply_model
         if hip_graph:
             from .graph import GraphedApplyModel
@@ -62,6 +66,24 @@ class DDIMSampler(object):
         self.register_buffer("ddim_sqrt_one_minus_alphas", np.sqrt(1. - np.asarray(ddim_alphas, dtype=np.float64)))
         self.register_buffer("ddim_sigmas_for_original_num_steps", ddim_eta * np.sqrt(
             (1 - self.ddim_alphas_prev) / (1 - self.ddim_alphas) * (1 - self.ddim_alphas / self.ddim_alphas_prev)))
+        self._time_table = None
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        if self.hoist_time and hasattr(unet, "time_embedding_table") and next(unet.parameters()).is_cuda:
+            # one [S, 1280] x [1280, 20160] pass per schedule instead of four launches per step
+            table = unet.time_embedding_table(np.ascontiguousarray(self.ddim_timesteps))
+            self._time_table = (table, {int(t): i for i, t in enumerate(self.ddim_timesteps)}, getattr(unet, "_generation", 0))
+
+    def _time_emb_kw(self, step):
+        """{'time_emb': row} for apply_model when the schedule's table holds `step` (and the weights it was built from
+        are still the UNet's), else {}."""
+        if self._time_table is None:
+            return {}
+        table, rows, gen = self._time_table
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        row = rows.get(int(step))
+        if row is None or getattr(unet, "_generation", 0) != gen:
+            return {}
+        return {"time_emb": table[row]}
 
     @torch.no_grad()
     def sample(self, n_steps=None, batch_size=None, shape=None, conditioning=None, callback=None,
@@ -133,7 +155,10 @@ class DDIMSampler(object):
             x_in = torch.cat([img, img]) if cfg else img
             # ONE UNet forward, batch 2B with CFG (cfg_pairs: rows b and b + B are the same latent and step - the UNet
             # computes what precedes its first cross-attention once per pair)
-            model_out = self._apply(x_in, ts, c_in, cfg_pairs=True) if (cfg and self.cfg_pairs) else self._apply(x_in, ts, c_in)
+            kw = self._time_emb_kw(step)
+            if cfg and self.cfg_pairs:
+                kw["cfg_pairs"] = True
+            model_out = self._apply(x_in, ts, c_in, **kw)
             sigma = float(self.ddim_sigmas[index])
             noise = torch.randn_like(img) * temperature if sigma > 0 else None
             img, pred_x0 = ops.ddim_step(

@@ -37,13 +37,18 @@ class DiffusionWrapper(nn.Module):
         self.conditioning_key = self.condition_key
 
     def forward(self, x, t, condition_concat=None, condition_cross_attn=None, condition_adm=None,
-                c_concat=None, c_crossattn=None, c_adm=None, cfg_pairs=False):
+                c_concat=None, c_crossattn=None, c_adm=None, cfg_pairs=False, time_emb=None):
         """ddpm.py:418-451 ('cross_attn' branch): context = cat(condition_cross_attn, dim=1)."""
         cross = condition_cross_attn if condition_cross_attn is not None else c_crossattn
         if self.condition_key is None:
             raise NotImplementedError("unconditional UNet (no context) is outside the SD2 hot path")
         ctx = cross[0] if len(cross) == 1 else torch.cat(list(cross), dim=1)
-        return self.diffusion_model(x, t, context=ctx, cfg_pairs=cfg_pairs) if cfg_pairs else self.diffusion_model(x, t, context=ctx)
+        kw = {}
+        if cfg_pairs:
+            kw["cfg_pairs"] = True
+        if time_emb is not None:
+            kw["time_emb"] = time_emb
+        return self.diffusion_model(x, t, context=ctx, **kw)
 
 
 class LatentDiffusion(nn.Module):
@@ -187,16 +192,20 @@ class LatentDiffusion(nn.Module):
         return enc(c) if callable(enc) else self.cond_stage_model(c)
 
     @torch.no_grad()
-    def apply_model(self, x_noisy, t, cond, return_ids=False, cfg_pairs=False):
+    def apply_model(self, x_noisy, t, cond, return_ids=False, cfg_pairs=False, time_emb=None):
         """-> DiffusionWrapper.forward -> UNetModel.forward.  cfg_pairs: the samplers' promise that
-        the batch is cat([x, x]) / cat([t, t]) (classifier-free guidance) - see UNetModel.forward."""
+        the batch is cat([x, x]) / cat([t, t]) (classifier-free guidance); time_emb: the samplers' precomputed row of
+        UNetModel.time_embedding_table() for step t - see UNetModel.forward."""
         if isinstance(cond, dict):
             return self.model(x_noisy, t, **cond)
         if not isinstance(cond, (list, tuple)):
             cond = [cond]
+        kw = {}
         if cfg_pairs:
-            return self.model(x_noisy, t, condition_cross_attn=list(cond), cfg_pairs=True)
-        return self.model(x_noisy, t, condition_cross_attn=list(cond))
+            kw["cfg_pairs"] = True
+        if time_emb is not None:
+            kw["time_emb"] = time_emb
+        return self.model(x_noisy, t, condition_cross_attn=list(cond), **kw)
 
     @torch.no_grad()
     def encode_first_stage(self, x):

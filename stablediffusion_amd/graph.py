@@ -16,11 +16,15 @@ class GraphedApplyModel:
         self.model = model
         self._key = None
         self._graph = None
-        self._x = self._t = self._out = self._cond = self._held = None
+        self._x = self._t = self._out = self._cond = self._held = self._temb = None
 
-    def _capture(self, x, t, cond, cfg_pairs=False):
+    def _capture(self, x, t, cond, cfg_pairs=False, time_emb=None):
         self._x, self._t, self._cond = x.clone(), t.clone(), cond
         kw = {"cfg_pairs": True} if cfg_pairs else {}
+        self._temb = None
+        if time_emb is not None:          # the per-step row of the samplers' time-embedding table: a static input
+            self._temb = time_emb.clone()
+            kw["time_emb"] = self._temb
         # warm-up on a side stream: packs weights, fills the cross-attention K/V cache, sets kernel attributes -
         # everything that must not happen inside a capture
         s = torch.cuda.Stream()
@@ -30,6 +34,10 @@ class GraphedApplyModel:
                 self.model.apply_model(self._x, self._t, self._cond, **kw)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # the warm-up stream's scratch arena (split-K slabs ...) would otherwise stay pinned under a stream handle nobody
+        # launches on again - one arena per re-capture
+        from . import ops
+        ops.release_scratch(stream=s.cuda_stream)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._out = self.model.apply_model(self._x, self._t, self._cond, **kw)
@@ -39,16 +47,19 @@ class GraphedApplyModel:
         self._held = (getattr(unet, "_pack", None), getattr(unet, "_ctx_cache", None))
         self._gen = getattr(unet, "_generation", 0)
 
-    def __call__(self, x, t, cond, cfg_pairs=False):
+    def __call__(self, x, t, cond, cfg_pairs=False, time_emb=None):
         if isinstance(cond, (dict, list, tuple)):
             return self.model.apply_model(x, t, cond)            # only the plain cross-attention form is captured
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         key = (tuple(x.shape), x.dtype, tuple(t.shape), cond.data_ptr(), tuple(cond.shape), cond._version,
-               getattr(unet, "_generation", 0), bool(cfg_pairs))       # new weights (load_state_dict / .to()) -> re-capture
+               getattr(unet, "_generation", 0), bool(cfg_pairs),       # new weights (load_state_dict / .to()) -> re-capture
+               None if time_emb is None else tuple(time_emb.shape))
         if key != self._key:
-            self._capture(x, t, cond, cfg_pairs)
+            self._capture(x, t, cond, cfg_pairs, time_emb)
             self._key = key
         self._x.copy_(x)
         self._t.copy_(t)
+        if time_emb is not None:
+            self._temb.copy_(time_emb)
         self._graph.replay()
         return self._out

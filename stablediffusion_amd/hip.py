@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 10    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 11    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -96,6 +96,8 @@ SIGNATURES = {
     "sdmi_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _i32, _vp]),
     "sdmi_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "sdmi_image_to_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp]),
+    "sdmi_probe_mfma": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), _vp]),
+    "sdmi_probe_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
 }
 
 _lib = None

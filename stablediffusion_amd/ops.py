@@ -42,6 +42,14 @@ def _scratch(nbytes, device):
     return buf
 
 
+def release_scratch(device=None, stream=None):
+    """Drop the scratch arenas (all of them, or those of one device / one stream handle).  They are re-created on
+    demand; callers that ran a warm-up on a throw-away stream (graph.py) release that stream's arena here so that it
+    does not stay pinned for the life of the process."""
+    for key in [k for k in _SCRATCH if (device is None or k[0] == device) and (stream is None or k[1] == stream)]:
+        del _SCRATCH[key]
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -300,6 +308,17 @@ def _run_gemm(a, what):
                   (int(a.M), int(a.N) * (2 if a.geglu else 1), int(a.K), int(a.stride), int(a.upsample))))
 
 
+_NARROW_MAX_CIN = 512     # csrc/sdmi_conv_narrow.hip NARROW_MAX_CIN
+
+
+def _narrow_conv_applies(a, pw):
+    """The conditions of sdmi_conv_narrow_launch that the caller controls (csrc/sdmi_conv_narrow.hip): conv3x3, stride 1,
+    <= 16 output channels, plain epilogue, Cin a multiple of 32 up to 512."""
+    return bool(a.mode == 1 and not FORCE_ALGO and pw.n_out <= 16 and a.stride == 1 and not a.upsample and not a.asym_pad
+                and not a.emb and not a.res and not a.act and not pw.geglu and a.Cin % 32 == 0 and a.Cin <= _NARROW_MAX_CIN
+                and a.H == a.Ho and a.W_in == a.Wo)
+
+
 def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m):
     a.W = pw.w.data_ptr()
     a.dtype = _dt(pw.dtype)
@@ -345,6 +364,10 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     if FORCE_TILE_M:
         a.tile_m = FORCE_TILE_M & ~1
         a.stages = 2 if FORCE_TILE_M & 1 else 3         # 129 = 128 rows, two stages
+    if _narrow_conv_applies(a, pw):
+        # <= 16 output channels: sdmi_gemm takes the byte-bound narrow kernel, which has no split-K form - a split
+        # picked for the tiled kernel's occupancy (the UNet `out` conv at batch 2: split 4) would route around it
+        sk = 1
     if sk > 1:
         nbytes = hip.lib().sdmi_gemm_workspace_bytes(m, n_w, sk)
         ws = _scratch(nbytes, out.device)

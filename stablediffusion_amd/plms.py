@@ -36,10 +36,10 @@ class PLMSSampler(DDIMSampler):
         def eps_at(x, step):
             n_in = 2 * b if cfg else b
             ts = torch.full((n_in,), int(step), device=device, dtype=torch.long)
+            kw = self._time_emb_kw(step)
             if cfg and getattr(self, "cfg_pairs", False):
-                out = self._apply(torch.cat([x, x]), ts, c_in, cfg_pairs=True).float()
-            else:
-                out = self._apply(torch.cat([x, x]) if cfg else x, ts, c_in).float()
+                kw["cfg_pairs"] = True
+            out = self._apply(torch.cat([x, x]) if cfg else x, ts, c_in, **kw).float()
             if cfg:
                 e_uc, e_c = out[:b].contiguous(), out[b:].contiguous()
                 return ops.lincomb([(1.0 - scale, e_uc), (scale, e_c)])

@@ -127,6 +127,66 @@ class SpatialTransformer(nn.Module):
             [BasicTransformerBlock(inner, n_heads, d_head, dropout, context_dim[d]) for d in range(depth)])
 
 
+@torch.no_grad()
+def pack_spatial_transformer(st, cd, kv_off=0):
+    """Packed weights of one SpatialTransformer for UNetModel._transformer: -> (entry, [to_k, to_v weights of its blocks, in
+    order], kv_off advanced).  The cross-attention K / V projections are returned unpacked because the UNet concatenates
+    those of all its transformers into ONE weight (one GEMM on the context); `kv_off` is this transformer's first column
+    in that concatenation.  project_in / proj_out may be nn.Linear (use_linear=True) or 1x1 nn.Conv2d (attention.py:213-226):
+    on NHWC activations both are the same [C_out, C_in] GEMM."""
+    f32 = lambda t: t.detach().float().contiguous()
+    e = {"norm": (f32(st.norm.weight), f32(st.norm.bias)),
+         "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias, dtype=cd),
+         "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias, dtype=cd), "blocks": []}
+    kv_w = []
+    for tb in st.transformer_blocks:
+        c = tb.attn1.to_q.weight.shape[0]
+        be = {
+            "ln1": (f32(tb.norm1.weight), f32(tb.norm1.bias)),
+            "ln2": (f32(tb.norm2.weight), f32(tb.norm2.bias)),
+            "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
+            "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd),
+            "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd),
+            "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd),
+            "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd),
+            "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd),
+            "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd),
+            "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
+        }
+        if tb.attn1.dim_head != 64:
+            raise NotImplementedError("sdmi_attention_d64 is built for head dim 64 (SD2: num_head_channels=64)")
+        kv_w += [tb.attn2.to_k.weight, tb.attn2.to_v.weight]
+        kv_off += 2 * c
+        e["blocks"].append(be)
+    return e, kv_w, kv_off
+
+
+def run_spatial_transformer(e, h, kv, nk, pair_prefix=False):
+    """SpatialTransformer.forward (attention.py:228-265) on an NHWC 16-bit image `h` [B, H, W, C] with the packed entry
+    `e` of pack_spatial_transformer; kv = the context's K | V projections ([B * nk, ...], this transformer's columns at
+    be["kv_off"]).  pair_prefix: `h` holds ONE row per classifier-free-guidance pair (UNetModel._forward_cfg_pairs);
+    the rows are duplicated right in front of the first cross-attention, the first op that sees the context."""
+    b, hh, ww, c = h.shape
+    n = hh * ww
+    xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False)
+    t = ops.linear(xn.reshape(b * n, c), e["pin"])
+    for bi, be in enumerate(e["blocks"]):
+        ci, heads = be["c"], be["heads"]
+        qkv = ops.linear(t, be["qkv1"], ln=be["ln1"])
+        a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
+        t = ops.linear(a, be["o1"], res=t)
+        if pair_prefix and bi == 0:
+            t, h, b = torch.cat([t, t]), torch.cat([h, h]), 2 * b
+        q2 = ops.linear(t, be["q2"], ln=be["ln2"])
+        ko = be["kv_off"]
+        a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
+        t = ops.linear(a, be["o2"], res=t)
+        g = ops.linear(t, be["geglu"], ln=be["ln3"])
+        t = ops.linear(g, be["ff2"], res=t)
+    out = ops.linear(t, e["pout"], res=h.reshape(b * n, c))
+    return out.reshape(b, hh, ww, c)
+
+
 class TimestepEmbeddingSequential(nn.Sequential):
     """Container only (openai_model.py:38-64); dispatch happens in UNetModel._run_block."""
 
@@ -319,29 +379,8 @@ class UNetModel(nn.Module):
         kv_w = []
         kv_off = 0
         for st in self._transformers():
-            e = {"norm": (f32(st.norm.weight), f32(st.norm.bias)),
-                 "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias, dtype=cd),
-                 "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias, dtype=cd), "blocks": []}
-            for tb in st.transformer_blocks:
-                c = tb.attn1.to_q.weight.shape[0]
-                be = {
-                    "ln1": (f32(tb.norm1.weight), f32(tb.norm1.bias)),
-                    "ln2": (f32(tb.norm2.weight), f32(tb.norm2.bias)),
-                    "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
-                    "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd),
-                    "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd),
-                    "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd),
-                    "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd),
-                    "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd),
-                    "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd),
-                    "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
-                }
-                if tb.attn1.dim_head != 64:
-                    raise NotImplementedError("sdmi_attention_d64 is built for head dim 64 (SD2: num_head_channels=64)")
-                kv_w += [tb.attn2.to_k.weight, tb.attn2.to_v.weight]
-                kv_off += 2 * c
-                e["blocks"].append(be)
-            pk[id(st)] = e
+            pk[id(st)], w, kv_off = pack_spatial_transformer(st, cd, kv_off)
+            kv_w += w
         pk["kv_all"] = ops.pack_linear_cat(kv_w, dtype=cd)
         for blk in list(self.input_blocks) + list(self.output_blocks):
             for layer in blk:
@@ -382,28 +421,7 @@ class UNetModel(nn.Module):
         return ops.conv3x3(n2, e["conv2"], res=sk)
 
     def _transformer(self, pk, st, h, kv, nk, pair_prefix=False):
-        """pair_prefix: `h` holds ONE row per classifier-free-guidance pair (see _forward_cfg_pairs); the rows are
-        duplicated right in front of the first cross-attention, the first op that sees the context."""
-        e = pk[id(st)]
-        b, hh, ww, c = h.shape
-        n = hh * ww
-        xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False)
-        t = ops.linear(xn.reshape(b * n, c), e["pin"])
-        for bi, be in enumerate(e["blocks"]):
-            ci, heads = be["c"], be["heads"]
-            qkv = ops.linear(t, be["qkv1"], ln=be["ln1"])
-            a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
-            t = ops.linear(a, be["o1"], res=t)
-            if pair_prefix and bi == 0:
-                t, h, b = torch.cat([t, t]), torch.cat([h, h]), 2 * b
-            q2 = ops.linear(t, be["q2"], ln=be["ln2"])
-            ko = be["kv_off"]
-            a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
-            t = ops.linear(a, be["o2"], res=t)
-            g = ops.linear(t, be["geglu"], ln=be["ln3"])
-            t = ops.linear(g, be["ff2"], res=t)
-        out = ops.linear(t, e["pout"], res=h.reshape(b * n, c))
-        return out.reshape(b, hh, ww, c)
+        return run_spatial_transformer(pk[id(st)], h, kv, nk, pair_prefix)
 
     def _run_block(self, pk, blk, h, skip, emb_all, kv, nk):
         for layer in blk:
@@ -452,12 +470,35 @@ class UNetModel(nn.Module):
         return h1, [torch.cat([h0, h0]), h1]
 
     @torch.no_grad()
-    def forward(self, x, time_steps=None, context=None, label=None, timesteps=None, y=None, cfg_pairs=False, **kwargs):
+    def _time_path(self, pk, t):
+        """int64 [n] -> fp32 [n, sum C_out]: sinusoid -> Linear -> SiLU -> Linear -> (SiLU, shared by all ResBlocks) ->
+        the 22 embedding projections as one GEMM (utils.py:292-328; openai_model.py:956-964, 280)."""
+        te = ops.timestep_embedding(t, self.model_channels, dtype=self.compute_dtype)
+        e1 = ops.linear(te, pk["te0"], act=1)
+        e2 = ops.linear(e1, pk["te2"], act=1)
+        return ops.linear(e2, pk["emb_all"], out_dtype=torch.float32)
+
+    @torch.no_grad()
+    def time_embedding_table(self, time_steps):
+        """The whole timestep path for a list of steps at once: int64 [S] -> fp32 [S, sum C_out], row s = what forward()
+        computes for time_steps == time_steps[s].  It depends on t only (openai_model.py:956-964, 280), and a sampler knows
+        all S steps of its schedule up front: it builds the table once per schedule and hands forward() one row per step
+        (`time_emb`), which removes the four launches of the time path from every step."""
+        pk = self._pack or self._build_pack()
+        dev = next(self.parameters()).device
+        t = torch.as_tensor(time_steps).to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+        return self._time_path(pk, t)
+
+    @torch.no_grad()
+    def forward(self, x, time_steps=None, context=None, label=None, timesteps=None, y=None, cfg_pairs=False,
+                time_emb=None, **kwargs):
         """x [B, C, h, w] (fp32/fp16/bf16 NCHW), time_steps int64 [B], context [B, Nk, context_dim]
         -> eps / v prediction, same shape and dtype as x (openai_model.py:940-1018).
         cfg_pairs=True is the caller's promise that x[B/2:] == x[:B/2] and time_steps[B/2:] == time_steps[:B/2] (a
         classifier-free-guidance batch): the part of the network in front of the first cross-attention then runs on
-        B/2 rows (_forward_cfg_pairs)."""
+        B/2 rows (_forward_cfg_pairs).  The promise covers x and time_steps only; it is ignored when a label is given.
+        time_emb: the row of time_embedding_table() that belongs to time_steps (all rows of the batch at the same step), or
+        [B, sum C_out] rows - the time path is then not run."""
         time_steps = time_steps if time_steps is not None else timesteps
         label = label if label is not None else y
         assert (label is not None) == (self.num_classes is not None), \
@@ -468,15 +509,23 @@ class UNetModel(nn.Module):
         t = time_steps.to(device=x.device, dtype=torch.int64).contiguous()
         if t.dim() == 0:
             t = t.expand(bsz).contiguous()
-        # time path: sinusoid -> Linear -> SiLU -> Linear -> (SiLU, shared by all ResBlocks) -> 22 projections
-        te = ops.timestep_embedding(t, self.model_channels, dtype=self.compute_dtype)
-        e1 = ops.linear(te, pk["te0"], act=1)
-        e2 = ops.linear(e1, pk["te2"], act=1)
-        emb_all = ops.linear(e2, pk["emb_all"], out_dtype=torch.float32)
+        if time_emb is not None:
+            # a row (or B rows) of time_embedding_table(): the caller's statement of what the time path yields for
+            # `time_steps`.  One row serves the whole batch through a zero batch stride (the conv epilogue reads
+            # emb[b * ld_emb + c]).
+            if not time_emb.is_cuda or time_emb.dtype != torch.float32 or time_emb.shape[-1] != pk["emb_all"].n_out:
+                raise ops.hip.SdmiError("time_emb: expected a device fp32 row of time_embedding_table()")
+            emb_all = time_emb.unsqueeze(0).expand(bsz, -1) if time_emb.dim() == 1 else time_emb
+            if emb_all.shape[0] != bsz or emb_all.stride(-1) != 1:
+                raise ops.hip.SdmiError("time_emb: expected [sum C_out] or [B, sum C_out] with unit inner stride")
+        else:
+            emb_all = self._time_path(pk, t)
         kv = self._context_kv(pk, context)
         nk = context.shape[1]
 
-        if cfg_pairs and bsz % 2 == 0 and bsz >= 2 and self._cfg_prefix_blocks() is not None:
+        # (label is None: with class / adm conditioning the two halves of a guidance pair may carry different y, so their
+        # time + label embeddings differ and the shared prefix would be wrong for rows B/2 onwards)
+        if cfg_pairs and label is None and bsz % 2 == 0 and bsz >= 2 and self._cfg_prefix_blocks() is not None:
             h, hs = self._forward_cfg_pairs(pk, x, emb_all, kv, nk)
             rest = list(self.input_blocks)[2:]
         else:

@@ -383,3 +383,27 @@ def test_txt2img_surface(tmp_path):
         txt2img.main(txt2img.parse_args(["--ipex"]))
     with pytest.raises(NotImplementedError):
         txt2img.main(txt2img.parse_args(["--dpm"]))
+
+
+def test_narrow_conv_is_never_split(lib):
+    """the UNet `out` conv (320 -> 4) at batch 2 / batch 1 got split-K 4 / 8 from the occupancy model, and
+    sdmi_gemm's narrow conv kernel has no split-K form - the launch then took the 128-column tiled kernel plus a reduce
+    pass for 4 real columns.  The host plan now pins split_k = 1 wherever the narrow kernel applies."""
+    import torch
+    from stablediffusion_amd import hip, ops
+    w = torch.randn(4, 320, 3, 3)
+    pw = ops.pack_conv3x3(w, torch.zeros(4), dtype=torch.float16)
+    for m_rows, side in ((8192, 64), (4096, 64), (2 * 32 * 32, 32)):
+        nb = m_rows // (side * side)
+        assert ops._plan_gemm(m_rows, 4, pw.k, pw.tile_n)[1] > 1          # what the tiled kernel would have been given
+        a = hip.GemmArgs()
+        a.mode, a.H, a.W_in, a.Cin, a.Ho, a.Wo, a.stride, a.M = 1, side, side, 320, side, side, 1, m_rows
+        out = torch.empty(nb, 4, side, side)
+        keep = ops._fill_common(a, pw, out, True, None, side * side, None, 0, 2, 1.0, m_rows)
+        assert keep is None and a.split_k == 1
+    # a conv the narrow kernel does not take keeps its split
+    w2 = torch.randn(320, 320, 3, 3)
+    pw2 = ops.pack_conv3x3(w2, torch.zeros(320), dtype=torch.float16)
+    a = hip.GemmArgs()
+    a.mode, a.H, a.W_in, a.Cin, a.Ho, a.Wo, a.stride, a.M = 1, 64, 64, 320, 64, 64, 1, 8192
+    assert not ops._narrow_conv_applies(a, pw2)

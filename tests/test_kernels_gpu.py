@@ -636,6 +636,29 @@ def test_attention_vae(dev, dt, nb, n, d, mode):
     assert rel_err(out.reshape(nb, n, d), ref) < (1.2e-2 if dt == BF16 else 2e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, BF16])
+@pytest.mark.parametrize("n,d", [(50, 64), (330, 512)])
+def test_attention_vae_standard_ragged_tile_with_negative_logits(dev, dt, n, d):
+    """Standard mode, N % 32 != 0, every logit of every row strongly negative (q = -k direction, large norm): the columns
+    past N in the last contraction tile have ZERO logits, i.e. they sit far ABOVE the row maximum; their weight must still
+    be exactly 0 (their V rows are zero), not exp2(-m) / l = inf (inf * 0 = NaN for the whole output row)."""
+    ops = _ops()
+    base = rnd((n, d), dev, 31)
+    base = base / base.norm(dim=-1, keepdim=True)
+    shared = torch.ones(d, device=dev) / d ** 0.5
+    # q.k = -(a^2) + small: logits around -a^2 * d^-0.5 * ... chosen so that scale * q.k ~ -60 (2^-86 as a weight base)
+    a = (60.0 * d ** 0.5) ** 0.5
+    q = (-a * shared + 0.3 * base).to(dt)
+    k = (a * shared + 0.3 * rnd((n, d), dev, 32) / d ** 0.5).to(dt)
+    v = rnd((n, d), dev, 33).to(dt)
+    out = ops.attention_vae(q.contiguous(), k.contiguous(), v.contiguous(), 1, n, d ** -0.5, "standard")
+    w = ((q.float() @ k.float().T) * d ** -0.5)
+    assert float(w.max()) < -30.0           # the case the clamp exists for
+    ref = w.softmax(-1) @ v.float()
+    assert bool(torch.isfinite(out.float()).all()), "ragged last tile produced inf * 0"
+    assert rel_err(out, ref) < (1.2e-2 if dt == BF16 else 2e-3)
+
+
 @pytest.mark.parametrize("mode", ["standard", "reference"])
 @pytest.mark.parametrize("nb,n,d", [(2, 100, 64), (1, 333, 128), (2, 256, 512)])
 def test_attention_vae_fp32_mode(dev, nb, n, d, mode):

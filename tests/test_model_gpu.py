@@ -667,3 +667,108 @@ def test_autoencoder_encode_decode_roundtrip_runs(dev):
     assert torch.allclose(zlat, post.mean * float(model.scale_factor), rtol=1e-6, atol=1e-7)
     img = model.decode_first_stage(zlat)
     assert img.shape == (2, 3, 32, 32) and bool(torch.isfinite(img).all())
+
+
+@pytest.mark.parametrize("variant", ["conv", "linear"])
+def test_spatial_transformer_d64_vs_reference_golden(dev, variant):
+    """SpatialTransformer with conv-1x1 project_in / proj_out (use_linear=False, attention.py:213-226) and with nn.Linear
+    ones, head dim 64, against outputs of the REFERENCE's own module (tests/golden/st_d64.npz, tools/gen_golden.py
+    --only-st-d64; B3 alias only).  On NHWC activations both variants are the same [C, C] GEMM - this pins that."""
+    from stablediffusion_amd import unet as U, ops
+    z = np.load(os.path.join(GOLD, "st_d64.npz"))
+    name = f"spatial_transformer_{variant}_d64"
+    st = U.SpatialTransformer(128, 2, 64, depth=1, context_dim=24, use_linear=(variant == "linear"))
+    pre = name + "/sd/"
+    st.load_state_dict({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)})
+    st = st.to(dev)
+    cd = torch.float16
+    e, kv_w, _ = U.pack_spatial_transformer(st, cd)
+    x, ctx = torch.from_numpy(z["in/img"]).to(dev), torch.from_numpy(z["in/ctx"]).to(dev)
+    kv = ops.linear(ops.cast_f32(ctx.reshape(-1, ctx.shape[-1]).contiguous(), cd), ops.pack_linear_cat(kv_w, dtype=cd))
+    out = U.run_spatial_transformer(e, ops.nchw_to_nhwc(x, dtype=cd), kv, ctx.shape[1])
+    err = rel_err(out.permute(0, 3, 1, 2), torch.from_numpy(z[name + "/out"]))
+    print(f"[parity] SpatialTransformer {variant} d64 fp16 vs reference golden: rel_err {err:.3e}")
+    assert err < NORTH_STAR
+
+
+def test_time_embedding_table_replaces_time_path(dev):
+    """The per-schedule hoist of the timestep path (openai_model.py:956-964, 280): a row of
+    UNetModel.time_embedding_table() handed to forward() as time_emb gives what forward() computes from time_steps itself
+    (fp32 table; the only difference is the summation order of a GEMM plan that depends on the row count), samplers with and
+    without the hoist agree, and the hipGraph replay takes the row as a static input."""
+    from stablediffusion_amd.ddim import DDIMSampler
+    model, _ = _latent_diffusion(dev, policy(synth.TINY_UNET, "fp16"), synth.TINY_DDCONFIG)
+    unet = model.model.diffusion_model
+    steps = torch.tensor([981, 501, 21, 1])
+    table = unet.time_embedding_table(steps)
+    assert table.dtype == torch.float32 and table.shape[0] == 4
+    x = synth.synth_input("tiny_x4", (4, 4, 16, 16)).to(dev)
+    ctx = synth.synth_input("tiny_ctx4", (4, 7, 96)).to(dev)
+    for i, s_ in enumerate(steps.tolist()):
+        t = torch.full((4,), s_, device=dev, dtype=torch.long)
+        own = unet(x, t, ctx)
+        hoisted = unet(x, t, ctx, time_emb=table[i])
+        assert rel_err(hoisted, own) < 2e-3, (s_, rel_err(hoisted, own))
+        rows = unet(x, t, ctx, time_emb=table[i].unsqueeze(0).expand(4, -1).contiguous())
+        assert torch.equal(rows, hoisted)
+    with pytest.raises(Exception):
+        unet(x, torch.full((4,), 1, device=dev, dtype=torch.long), ctx, time_emb=table[0][:-8])
+    x_T = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    c = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(6)).to(dev)
+    uc = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(7)).to(dev)
+    kw = dict(S=10, batch_size=2, shape=[4, 16, 16], conditioning=c, verbose=False, unconditional_guidance_scale=5.0,
+              unconditional_conditioning=uc, x_T=x_T)
+    hoist = DDIMSampler(model)
+    a, _ = hoist.sample(**kw)
+    assert hoist._time_table is not None and hoist._time_table[0].shape[0] == 10
+    b, _ = DDIMSampler(model, hoist_time=False).sample(**kw)
+    g, _ = DDIMSampler(model, hip_graph=True).sample(**kw)
+    print(f"[parity] ddim tiny 10-step, time path hoisted vs per step: latent rel_err {rel_err(a, b):.3e}")
+    assert rel_err(a, b) < 5e-3
+    assert torch.equal(a, g)
+
+
+@pytest.mark.slow
+def test_ddim_50_steps_512_free_running(dev):
+    """BASELINE.json configs[1] IN FULL: SD2 UNet + VAE, random-init, 512^2 (64x64 latent), batch 1, 50 DDIM steps with
+    classifier-free guidance 9.0, eta 0, fp16 - the HIP sampler (cfg_pairs prefix, hoisted time path: what bench.py
+    times) free-running against the CPU oracle on the same x_T / embeddings / weights.  SURVEY.md section 7 "hard part (d)":
+    error accumulation over 50 recurrent steps.  Semantics of the loop: ddim.py:105-249 as restated.
+    Prints the latent drift every 10 steps; gates: final latent relative error and decoded-image PSNR >= 35 dB."""
+    from oracle import sampler as OSamp
+    from stablediffusion_amd.ddim import DDIMSampler
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1)))
+    model, sd = _latent_diffusion(dev, policy(synth.SD2_UNET, "fp16"), synth.SD2_DDCONFIG, "eps")
+    unet_sd = {k[len("model.diffusion_model."):]: v for k, v in sd.items() if k.startswith("model.diffusion_model.")}
+    vae_sd = {k[len("first_stage_model."):]: v for k, v in sd.items() if k.startswith("first_stage_model.")}
+    x_T = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1234))
+    c = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(4321))
+    uc = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(99))
+    scale, S = 9.0, 50
+    acp = model.alphas_cumprod.cpu().numpy()
+    ref_x = {}
+    with torch.no_grad():
+        fn = lambda x, t, cond: OSamp.apply_model(unet_sd, synth.SD2_UNET, x, t, cond)
+        x_ref = OSamp.ddim_sample(fn, acp, S, x_T, c, uc, scale, 0.0, "eps",
+                                  record=lambda i, step, x, e_uc, e_c, xp: ref_x.__setitem__(i, xp.clone()))
+    sampler = DDIMSampler(model)
+    samples, inter = sampler.sample(S=S, batch_size=1, shape=[4, 64, 64], conditioning=c.to(dev), verbose=False,
+                                    unconditional_guidance_scale=scale, unconditional_conditioning=uc.to(dev), eta=0.0,
+                                    x_T=x_T.to(dev), log_every_t=10)
+    # x_inter = [x_T] + the latent after every step whose table index is 49 (the first) or a multiple of 10, i.e. after
+    # loop iterations i = 0, 9, 19, 29, 39, 49 - the oracle's record i holds its x_prev of the same iteration
+    logged = [i for i in range(S) if (S - i - 1) % 10 == 0 or i == 0]
+    assert len(inter["x_inter"]) == 1 + len(logged)
+    for i, xi in zip(logged, inter["x_inter"][1:]):
+        print(f"[parity] ddim-50 512^2 fp16 free-running: after step {i + 1:2d}/50 latent rel_err {rel_err(xi, ref_x[i]):.3e}")
+    free = rel_err(samples, x_ref)
+    img = model.decode_first_stage(samples)
+    with torch.no_grad():
+        img_ref = OSamp.decode_first_stage(vae_sd, synth.SD2_DDCONFIG, x_ref, 0.18215)
+    peak = float(img_ref.max() - img_ref.min())
+    p = psnr(img, img_ref, peak)
+    print(f"[parity] ddim-50 512^2 fp16 free-running: final latent rel_err {free:.3e}, decoded image PSNR {p:.1f} dB "
+          f"(peak-to-peak {peak:.3f})")
+    assert img.shape == (1, 3, 512, 512)
+    assert free < 5e-2, f"free-running 50-step latent relative error {free:.3e}"
+    assert p >= 35.0, f"decoded image PSNR {p:.1f} dB"

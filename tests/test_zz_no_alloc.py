@@ -76,3 +76,21 @@ def test_groupnorm_noalloc_rejects_oversize(dev):
                                     hip.DTYPE_F16, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert st == hip.SDMI_OK
+
+
+def test_groupnorm_noalloc_limit_counts_the_slabs_the_launch_uses(dev):
+    """512 images of 32 x 32 pixels run as the fused single launch (one slab entry per image: 512 <= 4096), although
+    sdmi_groupnorm_workspace_bytes() - an upper bound that always counts ceil(hw / 64) = 16 slabs here - exceeds the
+    array's size: the limit is the one include/sdmi.h states, not the workspace formula."""
+    from stablediffusion_amd import hip
+    lib = hip.lib()
+    nb, side, c = 512, 32, 64
+    assert lib.sdmi_groupnorm_workspace_bytes(nb, side * side) > 4096 * 32 * 3 * 4
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(nb, side, side, c, generator=g) * 1.3 - 0.2).to(torch.float16).to(dev)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    st_ref, ref = _call("sdmi_groupnorm", x, gamma, beta, 1e-6, 0, True)
+    st, out = _call("sdmi_groupnorm_noalloc", x, gamma, beta, 1e-6, 0, False)
+    assert st_ref == hip.SDMI_OK and st == hip.SDMI_OK
+    assert torch.equal(out, ref)

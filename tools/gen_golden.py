@@ -326,10 +326,32 @@ def gen_full_init8d(ref):
          **{"fp/" + k: v for k, v in fp.items()})
 
 
+@torch.no_grad()
+def gen_st_d64(ref):
+    """SpatialTransformer leaves with head dim 64 (the width the HIP attention kernel is built for; the leaf goldens of
+    gen_leaves use head dim 32): the conv-1x1 project_in / proj_out variant (use_linear=False, attention.py:213-226) and the
+    linear one, the reference's own module code (B3 alias only)."""
+    A = ref.attention
+    A.SpatialTransformer.proj_in = property(lambda s: s.project_in)
+    x_img = synth.synth_input("img128", (2, 128, 8, 8))
+    ctx = synth.synth_input("ctx", (2, 7, 24))
+    flat = {"in/img": x_img.numpy(), "in/ctx": ctx.numpy()}
+    for name, lin in (("spatial_transformer_conv_d64", False), ("spatial_transformer_linear_d64", True)):
+        m = A.SpatialTransformer(128, 2, 64, depth=1, context_dim=24, use_linear=lin, use_checkpoint=True).eval()
+        sd = seed_module(m, name + ".")
+        flat[f"{name}/out"] = m(x_img, ctx).numpy()
+        for k, v in sd.items():
+            flat[f"{name}/sd/{k}"] = v.numpy()
+    path = os.path.join(OUT, "st_d64.npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-init8d", action="store_true", help="write tests/golden/sd2_init8d_h32.npz only")
+    ap.add_argument("--only-st-d64", action="store_true", help="write tests/golden/st_d64.npz only")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -337,10 +359,14 @@ if __name__ == "__main__":
     if args.only_init8d:
         gen_full_init8d(reference)
         raise SystemExit(0)
+    if args.only_st_d64:
+        gen_st_d64(reference)
+        raise SystemExit(0)
     gen_leaves(reference)
     gen_tables(reference)
     gen_tiny_composites(reference)
     gen_tiny_encoder(reference)
+    gen_st_d64(reference)
     if args.full:
         gen_full(reference)
         gen_full_init8d(reference)
