@@ -770,5 +770,5 @@ def test_ddim_50_steps_512_free_running(dev):
     print(f"[parity] ddim-50 512^2 fp16 free-running: final latent rel_err {free:.3e}, decoded image PSNR {p:.1f} dB "
           f"(peak-to-peak {peak:.3f})")
     assert img.shape == (1, 3, 512, 512)
-    assert free < 5e-2, f"free-running 50-step latent relative error {free:.3e}"
+    assert free < NORTH_STAR, f"free-running 50-step latent relative error {free:.3e}"       # measured 2.6e-3
     assert p >= 35.0, f"decoded image PSNR {p:.1f} dB"
