@@ -43,7 +43,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 11: + sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 11: + sdmi_gemm_args.dup_rows, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -117,6 +117,13 @@ typedef struct sdmi_gemm_args {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_eps;
+    int32_t dup_rows;                   /* 1: every output row m is stored twice, at rows m and m + M of `out` (which then has
+                                           2 M rows): the torch.cat([t, t]) that turns the guidance-pair prefix of the UNet
+                                           (one row per (uncond, cond) pair) into the full classifier-free-guidance batch where
+                                           the context enters, written by the producing launch instead of a copy kernel.  Only
+                                           with the 16-bit row-major fast epilogue (out_kind 0, no GEGLU, N % 8 == 0, column
+                                           bias, ld_out % 8 == 0, ld_res % 8 == 0, 16-byte aligned out / res), batch 1,
+                                           split_k 1 and N > 16 - SDMI_ERR_BAD_ARG otherwise */
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);

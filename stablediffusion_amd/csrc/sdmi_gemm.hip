@@ -180,6 +180,14 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p.algo < 0 || p.algo > 2) return SDMI_ERR_BAD_ARG;
+    if (p.dup_rows != 0) {
+        // the second copy of every row is written by epilogue_rows16 only: the conditions under which every kernel
+        // (tiled, 256 x 256 x 32, panel without GEGLU) takes that epilogue
+        if (p.dup_rows != 1 || batch > 1 || split > 1 || p.geglu || p.out_kind != 0 || (p.N & 7) != 0 || p.N <= 16 ||
+            p.bias_per_row || ((p.ld_out | p.ld_res) & 7) != 0 || p.res_f32 ||
+            (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0)
+            return SDMI_ERR_BAD_ARG;
+    }
     if (p.ln_gamma != nullptr && (p.ln_beta == nullptr || p.algo == 1 || !(p.ln_eps >= 0.f))) return SDMI_ERR_BAD_ARG;
     if (p.ln_gamma == nullptr && p.ln_beta != nullptr) return SDMI_ERR_BAD_ARG;
     if (p.algo == 0 && p.mode == 1 && p.ln_gamma == nullptr) {      // conv3x3 with <= 16 output channels: the byte-bound narrow kernel

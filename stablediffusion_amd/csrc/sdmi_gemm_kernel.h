@@ -231,12 +231,18 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
             const auto sx = __builtin_amdgcn_permlane16_swap(ov[ni].x, ov[ni + 1].x, false, false);
             const auto sy = __builtin_amdgcn_permlane16_swap(ov[ni].y, ov[ni + 1].y, false, false);
             const int64_t n = ncol8 + ni * 16;
-            if (mval && n < p.N) *reinterpret_cast<uint4*>(outp + m * p.ld_out + n) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            if (mval && n < p.N) {
+                *reinterpret_cast<uint4*>(outp + m * p.ld_out + n) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (p.dup_rows) *reinterpret_cast<uint4*>(outp + (m + p.M) * p.ld_out + n) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
         }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const bool single = ni < P0 || (ni == TN - 1 && ((TN - P0) & 1));
-            if (single && mval && nval[ni]) *reinterpret_cast<uint2*>(outp + m * p.ld_out + ncol0 + ni * 16) = ov[ni];
+            if (single && mval && nval[ni]) {
+                *reinterpret_cast<uint2*>(outp + m * p.ld_out + ncol0 + ni * 16) = ov[ni];
+                if (p.dup_rows) *reinterpret_cast<uint2*>(outp + (m + p.M) * p.ld_out + ncol0 + ni * 16) = ov[ni];
+            }
         }
     }
 }

@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("stages", C.c_int32),
         ("algo", C.c_int32),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("dup_rows", C.c_int32),
     ]
 
 

@@ -364,6 +364,8 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     if FORCE_TILE_M:
         a.tile_m = FORCE_TILE_M & ~1
         a.stages = 2 if FORCE_TILE_M & 1 else 3         # 129 = 128 rows, two stages
+    if a.dup_rows:
+        sk = 1                  # the duplicated store lives in the fast 16-bit epilogue, not in the split-K reduce pass
     if _narrow_conv_applies(a, pw):
         # <= 16 output channels: sdmi_gemm takes the byte-bound narrow kernel, which has no split-K form - a split
         # picked for the tiled kernel's occupancy (the UNet `out` conv at batch 2: split 4) would route around it
@@ -383,12 +385,16 @@ FUSE_LN = True      # tests / tools: False runs the LayerNorm of linear(..., ln=
 
 
 def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True,
-           out_nchw_f32=None, ln=None):
+           out_nchw_f32=None, ln=None, dup_rows=False):
     """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat).
     ln = (gamma, beta[, eps]): out = epilogue(LayerNorm(x) @ W^T) - fused into the GEMM where the A-panel-stationary
     kernel applies (sdmi_gemm_panel_applies), a sdmi_layernorm launch in front of it elsewhere.
     out_dtype: None = the operand type, or torch.float32.  fp32 mode (pw.split_cp): x (and x2, res) are fp32, the
-    input is split into bf16 piece planes first and the output is fp32."""
+    input is split into bf16 piece planes first and the output is fp32.
+    dup_rows: the output has 2 M rows, rows [M, 2M) a copy of rows [0, M) (sdmi_gemm_args.dup_rows: the guidance-pair
+    duplication of the UNet written by the producing launch)."""
+    if dup_rows and (pw.split_cp or out_nchw_f32 is not None or (out_dtype is not None and out_dtype not in HALF_TYPES)):
+        raise hip.SdmiError("linear: dup_rows needs a 16-bit row-major output")
     if ln is not None and (pw.split_cp or x2 is not None or not FUSE_LN):
         x, ln = layernorm(x, *ln), None
     if pw.split_cp:
@@ -420,7 +426,11 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
         out = torch.empty(nb_, pw.n_out, hh_, ww_, dtype=torch.float32, device=x.device)
         keep = _fill_common(a, pw, out, bias, emb, hh_ * ww_, res, act, 2, alpha, m)
     else:
-        out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
+        if dup_rows:
+            a.dup_rows = 1
+            out = torch.empty(2 * m, pw.n_out, dtype=out_dtype, device=x.device)
+        else:
+            out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
         keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
     if ln is not None:
         gamma, beta = ln[0], ln[1]
@@ -438,7 +448,7 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     return out
 
 
-def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False, asym_pad=False):
+def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False, asym_pad=False, dup_rows=False):
     """3x3 conv, pad 1, on an NHWC bf16 image [B, H, W, Cin]; optional fused nearest-x2 input gather,
     time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC 16-bit, or fp32 NCHW.
     fp32 mode (pw.split_cp): x and res are fp32 NHWC, the output is fp32 NHWC."""
@@ -460,7 +470,12 @@ def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=Fa
     a.asym_pad = 1 if asym_pad else 0
     m = b * ho * wo
     a.M = m
-    if out_nchw_f32:
+    if dup_rows:            # images [b, 2b) of the output = a copy of images [0, b) (sdmi_gemm_args.dup_rows)
+        if out_nchw_f32 or pw.split_cp:
+            raise hip.SdmiError("conv3x3: dup_rows needs a 16-bit NHWC output")
+        a.dup_rows = 1
+        out = torch.empty(2 * b, ho, wo, pw.n_out, dtype=pw.dtype, device=x.device)
+    elif out_nchw_f32:
         out = torch.empty(b, pw.n_out, ho, wo, dtype=torch.float32, device=x.device)
     else:
         out = torch.empty(b, ho, wo, pw.n_out, dtype=torch.float32 if pw.split_cp else pw.dtype, device=x.device)

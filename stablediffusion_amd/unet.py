@@ -164,19 +164,33 @@ def pack_spatial_transformer(st, cd, kv_off=0):
 def run_spatial_transformer(e, h, kv, nk, pair_prefix=False):
     """SpatialTransformer.forward (attention.py:228-265) on an NHWC 16-bit image `h` [B, H, W, C] with the packed entry
     `e` of pack_spatial_transformer; kv = the context's K | V projections ([B * nk, ...], this transformer's columns at
-    be["kv_off"]).  pair_prefix: `h` holds ONE row per classifier-free-guidance pair (UNetModel._forward_cfg_pairs);
-    the rows are duplicated right in front of the first cross-attention, the first op that sees the context."""
+    be["kv_off"]).  pair_prefix: the second half of `h`'s images is a copy of the first (one classifier-free-guidance pair
+    per image of the first half, UNetModel._forward_cfg_pairs); everything in front of the first cross-attention - the first
+    op that sees the context - runs on the first half only."""
     b, hh, ww, c = h.shape
     n = hh * ww
+    h_full = h
+    if pair_prefix:
+        # `h` arrives with its rows already duplicated (images [b/2, b) are a copy of [0, b/2), written by the launch that
+        # produced it: ops.conv3x3(dup_rows=True)); what precedes the first cross-attention works on the first half
+        b //= 2
+        h = h[:b]
     xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False)
     t = ops.linear(xn.reshape(b * n, c), e["pin"])
     for bi, be in enumerate(e["blocks"]):
         ci, heads = be["c"], be["heads"]
         qkv = ops.linear(t, be["qkv1"], ln=be["ln1"])
         a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
-        t = ops.linear(a, be["o1"], res=t)
-        if pair_prefix and bi == 0:
-            t, h, b = torch.cat([t, t]), torch.cat([h, h]), 2 * b
+        dup = pair_prefix and bi == 0
+        # (dup: the output projection of the first self-attention stores every row twice - the duplication of the
+        # guidance pairs where the context enters, without a copy kernel)
+        if dup and t.dtype not in ops.HALF_TYPES:       # fp32 mode (built for the 1e-5 gate, not for speed): a plain copy
+            t = ops.linear(a, be["o1"], res=t)
+            t = torch.cat([t, t])
+        else:
+            t = ops.linear(a, be["o1"], res=t, dup_rows=dup)
+        if dup:
+            h, b = h_full, 2 * b
         q2 = ops.linear(t, be["q2"], ln=be["ln2"])
         ko = be["kv_off"]
         a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
@@ -407,7 +421,7 @@ class UNetModel(nn.Module):
         self._ctx_cache = (key, kv, context)   # keep `context` alive so data_ptr stays unique
         return kv
 
-    def _res_block(self, pk, r, h, skip, emb_all):
+    def _res_block(self, pk, r, h, skip, emb_all, dup_rows=False):
         e = pk[id(r)]
         emb = emb_all[:, e["emb_off"]:e["emb_off"] + r.out_channels]
         n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-5, True, x2=skip)
@@ -418,7 +432,7 @@ class UNetModel(nn.Module):
         else:
             assert skip is None
             sk = h
-        return ops.conv3x3(n2, e["conv2"], res=sk)
+        return ops.conv3x3(n2, e["conv2"], res=sk, dup_rows=dup_rows)
 
     def _transformer(self, pk, st, h, kv, nk, pair_prefix=False):
         return run_spatial_transformer(pk[id(st)], h, kv, nk, pair_prefix)
@@ -464,10 +478,17 @@ class UNetModel(nn.Module):
         half = x.shape[0] // 2
         emb_h = emb_all[:half]
         h = ops.nchw_to_nhwc(x[:half].float().contiguous(), dtype=self.compute_dtype)
-        h0 = ops.conv3x3(h, pk[id(b0[0])])
-        r = self._res_block(pk, b1[0], h0, None, emb_h)
+        # conv_in and the ResBlock's last conv store every image twice (sdmi_gemm_args.dup_rows): the full-batch tensors the
+        # skip connection and the transformer's residual need, without a copy kernel; the prefix itself reads the first half
+        if self.compute_dtype in ops.HALF_TYPES:
+            h0 = ops.conv3x3(h, pk[id(b0[0])], dup_rows=True)
+            r = self._res_block(pk, b1[0], h0[:half], None, emb_h, dup_rows=True)
+        else:                                           # fp32 mode: plain copies
+            h0 = ops.conv3x3(h, pk[id(b0[0])])
+            r = self._res_block(pk, b1[0], h0, None, emb_h)
+            h0, r = torch.cat([h0, h0]), torch.cat([r, r])
         h1 = self._transformer(pk, b1[1], r, kv, nk, pair_prefix=True)
-        return h1, [torch.cat([h0, h0]), h1]
+        return h1, [h0, h1]
 
     @torch.no_grad()
     def _time_path(self, pk, t):

@@ -368,6 +368,61 @@ def test_batched_gemm(dev):
 # ----------------------------------------------------------------------------- norms
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_dup_rows_store_is_a_bit_exact_copy(dev, dt, monkeypatch):
+    """sdmi_gemm_args.dup_rows: every output row stored at m and m + M - what torch.cat([t, t]) of the plain launch
+    gives, bit for bit - on every kernel whose fast 16-bit epilogue carries it: the tiled kernel (linear with bias +
+    residual, 128- and 160-column tiles; conv3x3 with bias + embedding + residual, incl. the 8-channel conv_in shape), the
+    256 x 256 x 32 tile and the A-panel-stationary kernel (K = 320 with a fused LayerNorm); refusals where the epilogue
+    does not apply."""
+    ops = _ops()
+    from stablediffusion_amd import hip
+    # linear, tiled kernel
+    for m, n, k in ((4096, 320, 320), (1000, 640, 192), (8192, 1280, 1280)):
+        x, w, b = rnd((m, k), dev, 1).to(dt), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+        res = rnd((m, n), dev, 4).to(dt)
+        pw = ops.pack_linear(w, b, dtype=dt)
+        one = ops.linear(x, pw, res=res)
+        two = ops.linear(x, pw, res=res, dup_rows=True)
+        assert two.shape == (2 * m, n) and torch.equal(two, torch.cat([one, one])), (m, n, k)
+    # the 256 x 256 x 32 tile
+    m, n, k = 16384, 1280, 2048
+    x, w = rnd((m, k), dev, 5).to(dt), rnd((n, k), dev, 6, k ** -0.5)
+    pw = ops.pack_linear(w, None, dtype=dt)
+    assert pw.w.shape[0] % 256 == 0
+    monkeypatch.setattr(ops, "FORCE_WIDE", 1)
+    one, two = ops.linear(x, pw), ops.linear(x, pw, dup_rows=True)
+    monkeypatch.setattr(ops, "FORCE_WIDE", 0)
+    assert torch.equal(two, torch.cat([one, one]))
+    # the panel kernel with its LayerNorm (K = 320, M >= 16384)
+    m = 16384
+    x, w, b = rnd((m, 320), dev, 7).to(dt), rnd((320, 320), dev, 8, 320 ** -0.5), rnd((320,), dev, 9)
+    ln = (1 + 0.1 * rnd((320,), dev, 10), 0.1 * rnd((320,), dev, 11))
+    pw = ops.pack_linear(w, b, dtype=dt)
+    one, two = ops.linear(x, pw, ln=ln), ops.linear(x, pw, ln=ln, dup_rows=True)
+    assert torch.equal(two, torch.cat([one, one]))
+    # conv3x3: ResBlock-shaped (bias + embedding + residual) and the conv_in shape (8 input channels)
+    for bsz, h, cin, cout in ((4, 32, 64, 320), (3, 64, 8, 320)):
+        xi = rnd((bsz, h, h, cin), dev, 12).to(dt)
+        wc, bc = rnd((cout, cin, 3, 3), dev, 13, (9 * cin) ** -0.5), rnd((cout,), dev, 14)
+        emb, res = rnd((bsz, cout), dev, 15), rnd((bsz, h, h, cout), dev, 16).to(dt)
+        pw = ops.pack_conv3x3(wc, bc, dtype=dt)
+        one = ops.conv3x3(xi, pw, emb=emb, res=res)
+        two = ops.conv3x3(xi, pw, emb=emb, res=res, dup_rows=True)
+        assert two.shape == (2 * bsz, h, h, cout) and torch.equal(two, torch.cat([one, one]))
+    # refused where the fast epilogue does not apply: fp32 output, GEGLU, a narrow conv
+    x = rnd((256, 320), dev, 17).to(dt)
+    pw = ops.pack_linear(rnd((320, 320), dev, 18), None, dtype=dt)
+    with pytest.raises(hip.SdmiError):
+        ops.linear(x, pw, out_dtype=torch.float32, dup_rows=True)
+    pg = ops.pack_geglu(rnd((2 * 320, 320), dev, 19), rnd((2 * 320,), dev, 20), dtype=dt)
+    with pytest.raises(hip.SdmiError):
+        ops.linear(x, pg, dup_rows=True)
+    pn = ops.pack_conv3x3(rnd((4, 64, 3, 3), dev, 21), None, dtype=dt)
+    with pytest.raises(hip.SdmiError):
+        ops.conv3x3(rnd((1, 16, 16, 64), dev, 22).to(dt), pn, dup_rows=True)
+
+
 @pytest.mark.parametrize("b,hw,c1,c2,silu,eps", [
     (2, 1024, 320, 0, True, 1e-5), (2, 256, 640, 320, True, 1e-5), (1, 64, 1280, 1280, True, 1e-5),
     (2, 4096, 128, 0, True, 1e-6), (1, 100, 1280, 640, False, 1e-6), (3, 70000, 128, 0, True, 1e-6),

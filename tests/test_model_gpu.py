@@ -8,7 +8,7 @@ Gates (BASELINE.json north_star):  relative error = max|a-b| /
 The benchmarked (headline) dtype is **fp16** - the operand type the reference's own v2-inference.yaml:24 selects
 (use_fp16: True) - and every fp16 case below is asserted at NORTH_STAR = 1e-2 (measured 1.3-2.7e-3).
 bf16 operands (use_bf16) run at the same MFMA rate and are kept as the secondary policy.  They are asserted at
-BF16_DOCUMENTED = 2.5e-2, NOT at the north-star figure: rounding ONLY the two operands of every contraction to bf16
+BF16_DOCUMENTED = 2.1e-2 (1.2 x the measured worst case), NOT at the north-star figure: rounding ONLY the two operands of every contraction to bf16
 (oracle.model.operand_precision - what an ideal bf16 MFMA with fp32 accumulators computes) already costs 0.8-1.4e-2
 against fp32 on these networks, and keeping the residual stream in bf16 as well (oracle.model.storage_precision - what
 this path does) costs 1.07-1.46e-2 in the CPU emulation (tools/precision_study.py, both weight recipes).
@@ -27,7 +27,9 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 NORTH_STAR = 1e-2
-BF16_DOCUMENTED = 2.5e-2      # secondary dtype only - see the module docstring; never applied to the headline dtype
+BF16_DOCUMENTED = 2.1e-2      # secondary dtype only - see the module docstring; never applied to the headline dtype.
+                              # = 1.2 x the worst bf16 figure measured over all cases of this file (1.75e-2: teacher-forced
+                              # v-prediction DDIM step; the others 0.88-1.63e-2), not a round number with slack
 HEADLINE = "fp16"             # the dtype bench.py reports
 BF16 = torch.bfloat16
 

@@ -31,6 +31,14 @@ SHAPES += [("linnr", (65536, 320, 640)), ("linnr", (65536, 320, 960)), ("lin", (
            ("linnr", (16384, 640, 1920)), ("linnr", (4096, 3840, 1280)), ("lin", (4096, 1280, 5120)), ("linnr", (4096, 1280, 2560)),
            ("linnr", (4096, 1280, 1920)), ("linnr", (1024, 1280, 2560)), ("linnr", (1024, 3840, 1280)), ("lin", (1024, 1280, 5120))]
 SHAPES += [("convout", (8, 512, 512, 128, 3)), ("convout", (16, 64, 64, 320, 4)), ("conv", (16, 16, 16, 640, 640)), ("lin", (1024, 1280, 1280)), ("conv", (16, 16, 16, 1920, 1280))]
+if os.environ.get("B1"):       # the UNet-batch-2 (BASELINE configs[1]) shapes: M = 8192 / 2048 / 512 / 128 tokens
+    SHAPES = [("lin", (8192, 320, 320)), ("linnr", (8192, 960, 320)), ("geglu", (8192, 1280, 320)), ("lin", (8192, 320, 1280)),
+              ("lin", (2048, 640, 640)), ("linnr", (2048, 1920, 640)), ("geglu", (2048, 2560, 640)), ("lin", (2048, 640, 2560)),
+              ("lin", (512, 1280, 1280)), ("linnr", (512, 3840, 1280)), ("geglu", (512, 5120, 1280)), ("lin", (512, 1280, 5120)),
+              ("lin", (128, 1280, 1280)), ("linnr", (128, 3840, 1280)), ("geglu", (128, 5120, 1280)), ("lin", (128, 1280, 5120)),
+              ("conv", (2, 64, 64, 320, 320)), ("conv", (2, 32, 32, 640, 640)), ("conv", (2, 16, 16, 1280, 1280)),
+              ("conv", (2, 8, 8, 1280, 1280)), ("conv", (2, 8, 8, 2560, 1280)), ("conv", (2, 16, 16, 2560, 1280)),
+              ("conv", (2, 32, 32, 1280, 640)), ("conv", (2, 64, 64, 640, 320))]
 if os.environ.get("CONFIGS"):      # CONFIGS=256:8,128:4  -> (tile_m, split) pairs; SHAPE=<substring of the shape tuple> filters
     configs = [(None, c.split(":")[1], c.split(":")[0]) for c in os.environ["CONFIGS"].split(",")]
 if os.environ.get("SHAPE"):
