@@ -130,8 +130,9 @@ int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
 /* 1 if this problem can run on the A-panel-stationary kernel (algo 2, or algo 0 with ln_gamma set), else 0. */
 int sdmi_gemm_panel_applies(const sdmi_gemm_args* args);
 /* 1 if this problem can run on the 256 x 256 x 32 tile (tile_n = 256): whole 64-deep k-tiles (mode 0: no K padding in
-   A; mode 1: Cin % 64 == 0), and either split_k > 1 or a plain 16-bit row-major epilogue (no GEGLU, N % 8 == 0, column
-   bias, 16-byte aligned out / res with ld % 8 == 0).  Has no say on whether W is padded to 256 rows. */
+   A; mode 1: Cin % 64 == 0), and either split_k > 1, a plain 16-bit row-major epilogue (N % 8 == 0, column bias, 16-byte
+   aligned out / res with ld % 8 == 0) or the 16-bit GEGLU epilogue (N % 32 == 0, no res / emb / act, batch 1).  Has no
+   say on whether W is padded to 256 rows. */
 int sdmi_gemm_wide_applies(const sdmi_gemm_args* args);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */

@@ -113,7 +113,11 @@ static bool wide_applies(const sdmi_gemm_args& p) {
         if (p.Cin % 64 != 0 || p.Cin > ZERO_ELEMS || p.K != 9 * (int64_t)p.Cin) return false;
     }
     if (split > 1) return true;
-    if (p.geglu || p.out_kind != 0 || (p.N & 7) != 0 || p.bias_per_row || (p.ld_out & 7) != 0) return false;
+    if (p.geglu) {      // the 16-bit GEGLU epilogue: nothing to add, whole 32-column output runs, no batching
+        return p.out_kind == 0 && p.res == nullptr && p.emb == nullptr && !p.bias_per_row && p.act == 0 && (p.N & 31) == 0 &&
+               (p.ld_out & 7) == 0 && (((uintptr_t)p.out) & 15) == 0 && batch == 1;
+    }
+    if (p.out_kind != 0 || (p.N & 7) != 0 || p.bias_per_row || (p.ld_out & 7) != 0) return false;
     if (p.res != nullptr && ((p.ld_res & 7) != 0 || p.res_f32)) return false;
     if ((((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0) return false;
     if (batch > 1 && (((p.stride_out | p.stride_res) & 7) != 0)) return false;

@@ -249,6 +249,43 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
 
 #undef SDMI_RES_LOAD_ROWBLOCK
 
+// GEGLU epilogue of one wave over FOUR 16-column weight blocks, 16-bit output (blocks (0,1) and (2,3) are (value, gate)
+// pairs; used by the panel kernel - TN == 4 - and, twice per wave, by the 256 x 256 x 32 tile): the two
+// gated 16-column blocks are paired through v_permlane16_swap - 16-byte stores, 64 contiguous bytes per row.
+template <int DT, int MI>
+__device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 (&acc)[4][MI], int64_t mrow, int64_t wcol_w,
+                                                 int fq) {
+    f32x4 bv[2], bg[2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int64_t wcol = wcol_w + pi * 32 + 4 * fq;
+        bv[pi] = bg[pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && wcol + 19 < 2 * p.N) {
+            bv[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol);
+            bg[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
+        }
+    }
+    const int64_t n = (wcol_w >> 1) + (fq & 1) * 16 + 4 * (fq & 2);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int64_t m = mrow + mi * 16;
+        uint2 ov[2];
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
+            v *= gelu_erf_f4(g);
+            ov[pi].x = elem_pack2<DT>(v[0], v[1]);
+            ov[pi].y = elem_pack2<DT>(v[2], v[3]);
+        }
+        const auto sx = __builtin_amdgcn_permlane16_swap(ov[0].x, ov[1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(ov[0].y, ov[1].y, false, false);
+        if (m < p.M && n < p.N)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out) + m * p.ld_out + n) =
+                make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    }
+}
+
+
 // One workgroup = 8 waves (4 x 2), block tile (64*MI) x (32*TN) x 64, one workgroup per CU (two waves per SIMD),
 // 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
 // (the 2-stage variant: two workgroups per CU).  The second __launch_bounds__ argument is waves per SIMD in HIP, not

@@ -41,41 +41,6 @@ __device__ __forceinline__ void wait_young(int young) {       // all but the `yo
     else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// GEGLU epilogue of one wave, 16-bit output (TN == 4: column blocks (0,1) and (2,3) are (value, gate) pairs): the two
-// gated 16-column blocks are paired through v_permlane16_swap - 16-byte stores, 64 contiguous bytes per row.
-template <int DT, int MI>
-__device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 (&acc)[4][MI], int64_t mrow, int64_t wcol_w,
-                                                 int fq) {
-    f32x4 bv[2], bg[2];
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-        const int64_t wcol = wcol_w + pi * 32 + 4 * fq;
-        bv[pi] = bg[pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr && wcol + 19 < 2 * p.N) {
-            bv[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol);
-            bg[pi] = *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
-        }
-    }
-    const int64_t n = (wcol_w >> 1) + (fq & 1) * 16 + 4 * (fq & 2);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int64_t m = mrow + mi * 16;
-        uint2 ov[2];
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
-            v *= gelu_erf_f4(g);
-            ov[pi].x = elem_pack2<DT>(v[0], v[1]);
-            ov[pi].y = elem_pack2<DT>(v[2], v[3]);
-        }
-        const auto sx = __builtin_amdgcn_permlane16_swap(ov[0].x, ov[1].x, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(ov[0].y, ov[1].y, false, false);
-        if (m < p.M && n < p.N)
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out) + m * p.ld_out + n) =
-                make_uint4(sx[0], sy[0], sx[1], sy[1]);
-    }
-}
-
 constexpr int panel_lds_bytes(int tn, int wmw, int kt, int nstw) { return (kt * wmw * 32 + nstw * tn * 32) * 128; }
 
 // WMW x 2 waves; block tile (32 * WMW) x (32 * TN); K = 64 * KT; NSTW-stage weight ring.

@@ -13,8 +13,8 @@
 //   * software pipeline over the two column halves of the wave tile (LO = blocks 0..3, HI = 4..7): after the barrier
 //     that publishes k-tile t + 1 the wave reads A(t + 1) and W_LO(t + 1), runs the held-back HI MFMAs of tile t, issues
 //     its DMA share of tile t + 4, reads W_HI(t + 1) and runs LO(t + 1); A fragments are double-buffered by parity;
-//   * epilogue: the 16-bit fast path of the tiled kernel (epilogue_rows16) or fp32 split-K slabs - the host takes this
-//     tile only where one of the two applies.
+//   * epilogue: the 16-bit fast path of the tiled kernel (epilogue_rows16), the 16-bit GEGLU epilogue (epilogue_geglu16)
+//     or fp32 split-K slabs - the host takes this tile only where one of the three applies.
 #pragma once
 #include "sdmi_gemm_kernel.h"
 
@@ -258,6 +258,13 @@ __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_
     // the wave's 128 columns as two runs of 64 (four 16-column blocks each): half the bias / residual / embedding
     // registers of one 8-block pass, which would spill beside the 128 accumulator registers
     typedef f32x4 (&half_t)[4][MI];
+    if (p.geglu) {
+        // (value, gate) pairs of 16-column weight blocks -> 64 gated output columns per wave, in two runs of 32
+        // (host-checked: 16-bit row-major output, nothing to add, N % 32 == 0)
+        epilogue_geglu16<DT, MI>(p, reinterpret_cast<half_t>(acc[0]), m0 + wm * 64 + frow, n0 + wn * 128, fq);
+        epilogue_geglu16<DT, MI>(p, reinterpret_cast<half_t>(acc[4]), m0 + wm * 64 + frow, n0 + wn * 128 + 64, fq);
+        return;
+    }
     epilogue_rows16<DT, 4, MI, 0>(p, reinterpret_cast<half_t>(acc[0]), m0 + wm * 64 + frow, n0 + wn * 128, fq, zoff_out, zoff_res);
     epilogue_rows16<DT, 4, MI, 0>(p, reinterpret_cast<half_t>(acc[4]), m0 + wm * 64 + frow, n0 + wn * 128 + 64, fq, zoff_out, zoff_res);
 }

@@ -234,7 +234,7 @@ def _wide_wins(m, n_w, nk, tile_n):
 
 
 @functools.lru_cache(maxsize=None)
-def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False):
+def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False):
     """(tile_m, split_k, stages, tile_n) from a small occupancy model, in microseconds.  A launch of B blocks puts
     ceil(B/256) blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed
     prologue/epilogue; splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to
@@ -243,6 +243,12 @@ def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False):
     one it has; _wide_wins decides."""
     nk = k // _BK
     if wide_ok and _wide_wins(m, n_w, nk, tile_n):
+        return (256, 1, 3, 256)
+    # GEGLU projections with a short K (levels 0 and 1 of the UNet: K = 320 | 640, many row tiles): half as many tiles,
+    # i.e. half as many prologues / epilogues, on the 256 x 256 x 32 tile - measured (tools/bench_gemm.py geglu, WIDE=0|1)
+    # 65536 x 2560 x 320 193 -> 170 us, 16384 x 5120 x 640 142 -> 132; at K = 1280 (4096 x 10240) it loses 3 % and stays
+    # on the 256 x 128 tile
+    if wide_ok and geglu and k <= 640 and math.ceil(m / 256) * math.ceil(n_w / 256) >= 1024:
         return (256, 1, 3, 256)
     # (Rounds 1 - 2 sent short K with many tiles to the two-stage 128-row variant - two blocks per CU, one block's epilogue
     # under the other's main loop.  Re-measured at the end of round 2 the 256-row tile beats it on every such shape:
@@ -356,7 +362,7 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     if wide_ok:
         a.tile_n, a.split_k = 256, 1
         wide_ok = bool(hip.lib().sdmi_gemm_wide_applies(C.byref(a)))
-    a.tile_m, sk, a.stages, a.tile_n = _plan_gemm(m, n_w, pw.k, pw.tile_n, wide_ok)
+    a.tile_m, sk, a.stages, a.tile_n = _plan_gemm(m, n_w, pw.k, pw.tile_n, wide_ok, bool(pw.geglu))
     if FORCE_WIDE and wide_ok:
         a.tile_m, sk, a.tile_n = 256, 1, 256
     if _auto_split_k is not _AUTO_SPLIT_K or a.tile_n != 256:

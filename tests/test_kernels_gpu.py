@@ -260,6 +260,33 @@ def test_wide_tile_256x256x32(dev, dt, monkeypatch):
     assert ops.hip.lib().sdmi_gemm(C.byref(a), None) != 0
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_wide_tile_geglu_epilogue(dev, dt, monkeypatch):
+    """GEGLU on the 256 x 256 x 32 tile (value / gate column blocks paired inside a wave, two runs of 32 gated columns per
+    wave) against the tiled kernel and the fp32 formula value * gelu_erf(gate) (attention.py:72-91): ragged M, the three
+    UNet widths."""
+    ops = _ops()
+    tol = 8e-3 if dt == BF16 else 2e-3
+    for m, inner, k in ((1000, 512, 320), (4096, 1280, 320), (777, 2560, 640), (520, 5120, 1280)):
+        x = rnd((m, k), dev, 1).to(dt)
+        w, b = rnd((2 * inner, k), dev, 2, k ** -0.5), rnd((2 * inner,), dev, 3)
+        pw = ops.pack_geglu(w, b, dtype=dt)
+        assert pw.w.shape[0] % 256 == 0
+        monkeypatch.setattr(ops, "FORCE_WIDE", 0)
+        monkeypatch.setattr(ops, "WIDE_TILE", False)
+        tiled = ops.linear(x, pw)
+        monkeypatch.setattr(ops, "FORCE_WIDE", 1)
+        monkeypatch.setattr(ops, "WIDE_TILE", True)
+        a = ops.hip.GemmArgs()
+        wide = ops.linear(x, pw)
+        monkeypatch.setattr(ops, "FORCE_WIDE", 0)
+        y = F.linear(x.float(), w.to(dt).float(), b)
+        ref = y[:, :inner] * F.gelu(y[:, inner:])
+        assert wide.shape == (m, inner)
+        assert rel_err(wide, tiled) < tol, (m, inner, k)
+        assert rel_err(wide, ref) < tol, (m, inner, k)
+
+
 def test_plan_takes_the_wide_tile_only_where_measured(dev):
     ops = _ops()
     assert ops._plan_gemm(4096, 3840, 1280, 160, True)[3] == 256          # level-2 qkv: 55 -> 43 us
@@ -267,6 +294,10 @@ def test_plan_takes_the_wide_tile_only_where_measured(dev):
     assert ops._plan_gemm(4096, 1280, 11520, 160, True)[3] == 160         # 80 wide tiles: split-K on the small tile wins
     assert ops._plan_gemm(65536, 1280, 320, 160, True)[3] == 160          # short K: not measured
     assert ops._plan_gemm(4096, 3840, 1280, 160, False)[3] == 160
+    assert ops._plan_gemm(65536, 2560, 320, 128, True, True)[3] == 256        # level-0 GEGLU: 193 -> 170 us
+    assert ops._plan_gemm(16384, 5120, 640, 128, True, True)[3] == 256        # level-1 GEGLU: 142 -> 132 us
+    assert ops._plan_gemm(4096, 10240, 1280, 128, True, True)[3] == 128       # level-2 GEGLU: the wide tile loses 3 %
+    assert ops._plan_gemm(8192, 2560, 320, 128, True, True)[3] == 128         # batch 1: not measured
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,ups", [
