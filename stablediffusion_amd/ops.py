@@ -446,6 +446,8 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
             raise hip.SdmiError("linear: LayerNorm parameters do not match K")
         if hip.lib().sdmi_gemm_panel_applies(C.byref(a)):
             a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), ln[2] if len(ln) > 2 else 1e-5
+            if a.tile_n == 256:       # the plan's 256 x 256 x 32 tile gives way to the kernel that carries the LayerNorm
+                a.tile_n, a.tile_m = pw.tile_n, 0
         else:
             xn = layernorm(x, *ln)
             a.A = xn.data_ptr()
