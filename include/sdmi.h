@@ -39,11 +39,13 @@ typedef enum sdmi_status {
  * policy (openai_model.py:602-603: use_fp16 -> float16, use_bf16 -> bfloat16); both run at the same MFMA rate. */
 typedef enum sdmi_dtype {
     SDMI_DTYPE_BF16 = 0, SDMI_DTYPE_F16 = 1,
-    SDMI_DTYPE_F32_PLANES = 2    /* sdmi_pack_* only: the six bf16 piece planes of the fp32 mode (see sdmi_f32_split3) */
+    SDMI_DTYPE_F32_PLANES = 2,   /* sdmi_pack_* only: the six bf16 piece planes of the fp32 mode (see sdmi_f32_split3) */
+    SDMI_DTYPE_F16_TO_BF16 = 3   /* sdmi_groupnorm / sdmi_groupnorm_noalloc / sdmi_layernorm only: input f16 (the residual
+                                    stream of the bf16 operand policy), output bf16 (an MFMA operand) */
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 11: + sdmi_gemm_args.dup_rows, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -117,6 +119,11 @@ typedef struct sdmi_gemm_args {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_eps;
+    int32_t out_f16, res_f16, a_f16;    /* dtype == SDMI_DTYPE_BF16 only (SDMI_ERR_BAD_ARG with f16 operands, where they would change
+                                           nothing): the bf16 operand policy keeps its RESIDUAL STREAM in f16 - same bytes, three more
+                                           significant bits - so that only the MFMA operands carry bf16 rounding.
+                                           out_f16: `out` (out_kind 0) is stored as f16; res_f16: `res` holds f16; a_f16: A holds f16 -
+                                           only together with ln_gamma, whose LayerNorm then writes the bf16 operand */
     int32_t dup_rows;                   /* 1: every output row m is stored twice, at rows m and m + M of `out` (which then has
                                            2 M rows): the torch.cat([t, t]) that turns the guidance-pair prefix of the UNet
                                            (one row per (uncond, cond) pair) into the full classifier-free-guidance batch where

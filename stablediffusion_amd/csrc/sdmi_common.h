@@ -109,6 +109,29 @@ template <int DT> __device__ __forceinline__ void elem_unpack4(const uint2& v, f
     f[0] = elem_to_f32<DT>((unsigned short)(v.x & 0xffffu)); f[1] = elem_to_f32<DT>((unsigned short)(v.x >> 16));
     f[2] = elem_to_f32<DT>((unsigned short)(v.y & 0xffffu)); f[3] = elem_to_f32<DT>((unsigned short)(v.y >> 16));
 }
+// The bf16 operand policy keeps its residual stream in f16 (include/sdmi.h, sdmi_gemm_args.out_f16 / res_f16 / a_f16):
+// in a kernel instantiated for bf16 operands (DT == 0) a residual / output / LayerNorm input may be f16, chosen at run
+// time by a wave-uniform flag.  Kernels instantiated for f16 operands (DT == 1) compile to exactly what they were.
+template <int DT> __device__ __forceinline__ unsigned elem_pack2_sel(float lo, float hi, int f16) {
+    if constexpr (DT == 0) { if (f16) return elem_pack2<1>(lo, hi); }
+    return elem_pack2<DT>(lo, hi);
+}
+template <int DT> __device__ __forceinline__ void elem_unpack4_sel(const uint2& v, float* f, int f16) {
+    if constexpr (DT == 0) { if (f16) { elem_unpack4<1>(v, f); return; } }
+    elem_unpack4<DT>(v, f);
+}
+template <int DT> __device__ __forceinline__ void elem_unpack8_sel(const uint4& v, float* f, int f16) {
+    if constexpr (DT == 0) { if (f16) { elem_unpack8<1>(v, f); return; } }
+    elem_unpack8<DT>(v, f);
+}
+template <int DT> __device__ __forceinline__ float elem_to_f32_sel(unsigned short b, int f16) {
+    if constexpr (DT == 0) { if (f16) return elem_to_f32<1>(b); }
+    return elem_to_f32<DT>(b);
+}
+template <int DT> __device__ __forceinline__ unsigned short elem_from_f32_sel(float f, int f16) {
+    if constexpr (DT == 0) { if (f16) return elem_from_f32<1>(f); }
+    return elem_from_f32<DT>(f);
+}
 template <int DT> __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
     if constexpr (DT == 0)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);

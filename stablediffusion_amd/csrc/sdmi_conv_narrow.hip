@@ -158,6 +158,7 @@ template <int DT> kern_t pick(int cs) {
 int sdmi_conv_narrow_launch(const sdmi_gemm_args& p, hipStream_t s) {
     if (p.mode != 1 || p.N > 16 || p.N <= 0 || p.stride != 1 || p.upsample != 0 || p.asym_pad != 0) return 0;
     if (p.batch > 1 || p.split_k > 1 || p.emb != nullptr || p.res != nullptr || p.act != 0 || p.geglu || p.bias_per_row) return 0;
+    if (p.out_f16 || p.dup_rows) return 0;      // (epilogue options of the tiled kernel only)
     if (p.Cin % 32 != 0 || p.Cin > NARROW_MAX_CIN || p.K < 9 * (int64_t)p.Cin || p.K % 8 != 0) return 0;
     if (p.H != p.Ho || p.W_in != p.Wo || p.M >= (1LL << 31)) return 0;
     if (p.out_kind == 0 && (p.ld_out % 4 != 0)) return 0;

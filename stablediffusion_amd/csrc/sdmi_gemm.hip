@@ -184,6 +184,14 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p.algo < 0 || p.algo > 2) return SDMI_ERR_BAD_ARG;
+    if ((p.out_f16 | p.res_f16 | p.a_f16) != 0) {
+        // the f16 residual stream of the bf16 operand policy
+        if (p.dtype != SDMI_DTYPE_BF16 || (p.out_f16 & ~1) || (p.res_f16 & ~1) || (p.a_f16 & ~1)) return SDMI_ERR_BAD_ARG;
+        if (p.out_f16 && p.out_kind != 0) return SDMI_ERR_BAD_ARG;
+        if (p.res_f16 && (p.res == nullptr || p.res_f32)) return SDMI_ERR_BAD_ARG;
+        if (p.a_f16 && p.ln_gamma == nullptr) return SDMI_ERR_BAD_ARG;      // only a LayerNorm converts the operand
+        if (p.out_f16 && p.geglu) return SDMI_ERR_BAD_ARG;                  // a GEGLU output is an operand, never the stream
+    }
     if (p.dup_rows != 0) {
         // the second copy of every row is written by epilogue_rows16 only: the conditions under which every kernel
         // (tiled, 256 x 256 x 32, panel without GEGLU) takes that epilogue

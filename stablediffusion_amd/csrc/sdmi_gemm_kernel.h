@@ -84,22 +84,22 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
         if (full) {
             const uint2 rv = *reinterpret_cast<const uint2*>(r);
             float rf[4];
-            elem_unpack4<DT>(rv, rf);
+            elem_unpack4_sel<DT>(rv, rf, p.res_f16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += rf[j];
         } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += elem_to_f32<DT>(r[j]);
+            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += elem_to_f32_sel<DT>(r[j], p.res_f16);
         }
     }
     if (p.out_kind == 0) {
         unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n;
         if (full) {
             uint2 ov;
-            ov.x = elem_pack2<DT>(v[0], v[1]);
-            ov.y = elem_pack2<DT>(v[2], v[3]);
+            ov.x = elem_pack2_sel<DT>(v[0], v[1], p.out_f16);
+            ov.y = elem_pack2_sel<DT>(v[2], v[3], p.out_f16);
             *reinterpret_cast<uint2*>(o) = ov;
         } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = elem_from_f32<DT>(v[j]);
+            for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] = elem_from_f32_sel<DT>(v[j], p.out_f16);
         }
     } else if (p.out_kind == 1) {
         float* o = reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n;
@@ -219,12 +219,12 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
             if (p.emb != nullptr) v += eq[ni];
             if (p.res != nullptr) {
                 float rf[4];
-                elem_unpack4<DT>(rq[ni], rf);
+                elem_unpack4_sel<DT>(rq[ni], rf, p.res_f16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rf[j];
             }
-            ov[ni].x = elem_pack2<DT>(v[0], v[1]);
-            ov[ni].y = elem_pack2<DT>(v[2], v[3]);
+            ov[ni].x = elem_pack2_sel<DT>(v[0], v[1], p.out_f16);
+            ov[ni].y = elem_pack2_sel<DT>(v[2], v[3], p.out_f16);
         }
 #pragma unroll
         for (int ni = P0; ni + 1 < TN; ni += 2) {
@@ -646,14 +646,14 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 if (p.emb != nullptr) v += eq[ni];
                 if (p.res != nullptr) {
                     float rf[4];
-                    elem_unpack4<DT>(rq[ni], rf);
+                    elem_unpack4_sel<DT>(rq[ni], rf, p.res_f16);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += rf[j];
                 }
                 if (p.out_kind == 0) {
                     uint2 ov;
-                    ov.x = elem_pack2<DT>(v[0], v[1]);
-                    ov.y = elem_pack2<DT>(v[2], v[3]);
+                    ov.x = elem_pack2_sel<DT>(v[0], v[1], p.out_f16);
+                    ov.y = elem_pack2_sel<DT>(v[2], v[3], p.out_f16);
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + zoff_out + m * p.ld_out + n) = ov;
                 } else {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + zoff_out + m * p.ld_out + n) = v;

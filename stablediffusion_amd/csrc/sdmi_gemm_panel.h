@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WMW * 128, 2) void sdmi_gemm_panel_kernel(const sdm
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint4 raw = ldsw[kt * A_KT_CHUNKS + row * 8 + ((part + 4 * h) ^ (row & 7))];
-                elem_unpack8<DT>(raw, f[2 * kt + h]);
+                elem_unpack8_sel<DT>(raw, f[2 * kt + h], p.a_f16);      // (bf16 policy: the rows are the f16 residual stream)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += f[2 * kt + h][j];
             }

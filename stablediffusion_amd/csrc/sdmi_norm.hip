@@ -50,7 +50,7 @@ __device__ __forceinline__ int64_t p_end_of(int slab, int64_t P, int64_t hw) {
 
 // y = silu?(x * scale[c] + shift[c]) over pixels [p_begin, p_end) x channels [c0, c0 + Cw) of image b; scale/shift
 // tables are built in LDS (sh[2*Cw]) from grp_stat[g_local] = (mean, rstd).  Called by every thread of the block.
-template <int DT>
+template <int DTI, int DTO>
 __device__ __forceinline__ void gn_apply_stream(const unsigned short* __restrict__ x1, const unsigned short* __restrict__ x2,
                                                 int C1, int C2, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const float* grp_stat,
@@ -81,26 +81,26 @@ __device__ __forceinline__ void gn_apply_stream(const unsigned short* __restrict
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float f[8];
-                elem_unpack8<DT>(raw[u], f);
+                elem_unpack8<DTI>(raw[u], f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float y = f[j] * sc[j] + sf[j];
                     f[j] = silu ? silu_f(y) : y;
                 }
-                *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix + u * rows) * C + c0 + v * 8) = elem_pack8<DT>(f);
+                *reinterpret_cast<uint4*>(out + ((int64_t)b * hw + pix + u * rows) * C + c0 + v * 8) = elem_pack8<DTO>(f);
             }
         }
         for (; pix < p_end; pix += rows) {
             const int64_t gp = (int64_t)b * hw + pix;
             const uint4 raw = gn_load(x1, x2, C1, C2, gp, v0 + v);
             float f[8];
-            elem_unpack8<DT>(raw, f);
+            elem_unpack8<DTI>(raw, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float y = f[j] * sc[j] + sf[j];
                 f[j] = silu ? silu_f(y) : y;
             }
-            *reinterpret_cast<uint4*>(out + gp * C + c0 + v * 8) = elem_pack8<DT>(f);
+            *reinterpret_cast<uint4*>(out + gp * C + c0 + v * 8) = elem_pack8<DTO>(f);
         }
     }
 }
@@ -109,7 +109,7 @@ __device__ __forceinline__ void gn_apply_stream(const unsigned short* __restrict
 // low-resolution tensors (8x8, 16x16: one or four slabs per image) still fill the chip.
 // FUSED (one slab per image: the block sees every pixel of its groups): statistics and apply in ONE launch - the
 // second read of x comes from L2.  Otherwise the block writes its (n, mean, M2) partials for gn_apply_kernel.
-template <int DT, bool FUSED>
+template <int DTI, int DTO, bool FUSED>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned short* __restrict__ x1,
                                                               const unsigned short* __restrict__ x2, int C1, int C2,
                                                               int64_t hw, int64_t P, float* __restrict__ partial,
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float f[8];
-                    elem_unpack8<DT>(raw[u], f);
+                    elem_unpack8<DTI>(raw[u], f);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
                 }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
             for (; pix < p_end; pix += rows) {
                 const uint4 raw = gn_load(x1, x2, C1, C2, (int64_t)b * hw + pix, v0 + v);
                 float f[8];
-                elem_unpack8<DT>(raw, f);
+                elem_unpack8<DTI>(raw, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
             }
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const unsigned sho
     }
     if (FUSED) {
         __syncthreads();      // grp_stat visible; the per-row sums in `sh` are dead and become the scale/shift tables
-        gn_apply_stream<DT>(x1, x2, C1, C2, gamma, beta, &grp_stat[0][0], out, hw, p_begin, p_end, b, blockIdx.z * Cw, Cw,
+        gn_apply_stream<DTI, DTO>(x1, x2, C1, C2, gamma, beta, &grp_stat[0][0], out, hw, p_begin, p_end, b, blockIdx.z * Cw, Cw,
                             cpg, silu, sh);
     }
 }
 
-template <int DT>
+template <int DTI, int DTO>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned short* __restrict__ x1,
                                                               const unsigned short* __restrict__ x2, int C1, int C2,
                                                               const float* __restrict__ gamma,
@@ -261,16 +261,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const unsigned sho
         grp_stat[tid][1] = rsqrtf(m2 / n + eps);
     }
     __syncthreads();
-    gn_apply_stream<DT>(x1, x2, C1, C2, gamma, beta, &grp_stat[0][0], out, hw, p_begin_of(slab, P), p_end_of(slab, P, hw),
+    gn_apply_stream<DTI, DTO>(x1, x2, C1, C2, gamma, beta, &grp_stat[0][0], out, hw, p_begin_of(slab, P), p_end_of(slab, P, hw),
                         b, c0, Cw, cpg, silu, sh);
 }
+
+template <int DTI, int DTO> constexpr auto gn_stats_fused = gn_stats_kernel<DTI, DTO, true>;
+template <int DTI, int DTO> constexpr auto gn_stats_split = gn_stats_kernel<DTI, DTO, false>;
 
 // LayerNorm: LPR lanes per row (a power of two <= 64 chosen by the host so that C/8 vectors split evenly, e.g.
 // C = 320 -> 8 lanes x 5 vectors, and a wave covers 64/LPR rows), row held in registers, exact two-pass statistics
 // with the reductions inside the LPR-lane group.  Consecutive lanes of a group read consecutive 16-byte vectors.
 constexpr int LN_MAXV = 5;   // vectors per lane
 
-template <int DT>
+template <int DTI, int DTO>
 __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
             const int v = li + lpr * i;
             if (v < nvec) {
                 const uint4 raw = *reinterpret_cast<const uint4*>(xr + v * 8);
-                elem_unpack8<DT>(raw, f[i]);
+                elem_unpack8<DTI>(raw, f[i]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += f[i][j];
             }
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
                     y[j] = (f[i][j] - mean) * rstd * g0[j] + b0[j];
                     y[4 + j] = (f[i][4 + j] - mean) * rstd * g1[j] + b1[j];
                 }
-                *reinterpret_cast<uint4*>(orow + v * 8) = elem_pack8<DT>(y);
+                *reinterpret_cast<uint4*>(orow + v * 8) = elem_pack8<DTO>(y);
             }
         }
     }
@@ -353,7 +356,7 @@ static int64_t gn_launch_slabs(int64_t hw) {
 // Argument checks shared by the two GroupNorm entry points (everything except the scratch buffer).
 static int groupnorm_check(const void* x1, const void* x2, int32_t C1, int32_t C2, const float* gamma, const float* beta,
                            const void* out, int32_t nb, int64_t hw, int32_t dtype) {
-    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
+    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16 && dtype != SDMI_DTYPE_F16_TO_BF16) return SDMI_ERR_BAD_ARG;
     if (x1 == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (nb <= 0 || hw <= 0 || C1 <= 0 || C2 < 0) return SDMI_ERR_BAD_ARG;
     if ((x2 == nullptr) != (C2 == 0)) return SDMI_ERR_BAD_ARG;
@@ -385,24 +388,23 @@ static int groupnorm_launch(const void* x1, const void* x2, int32_t C1, int32_t 
     const unsigned short* u1 = reinterpret_cast<const unsigned short*>(x1);
     const unsigned short* u2 = reinterpret_cast<const unsigned short*>(x2);
     unsigned short* uo = reinterpret_cast<unsigned short*>(out);
+    // (input type, output type): bf16 -> bf16, f16 -> f16, or f16 -> bf16 (the f16 residual stream of the bf16 operand policy)
+#define SDMI_GN_LAUNCH(KERNEL, LDS, ...)                                                                            \
+    do {                                                                                                            \
+        if (dtype == SDMI_DTYPE_F16)      hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(GN_THREADS), LDS, s, __VA_ARGS__); \
+        else if (dtype == SDMI_DTYPE_BF16) hipLaunchKernelGGL((KERNEL<0, 0>), grid, dim3(GN_THREADS), LDS, s, __VA_ARGS__); \
+        else                              hipLaunchKernelGGL((KERNEL<1, 0>), grid, dim3(GN_THREADS), LDS, s, __VA_ARGS__); \
+    } while (0)
     if (fused) {
-        if (dtype == SDMI_DTYPE_F16)
-            hipLaunchKernelGGL((gn_stats_kernel<1, true>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
-        else
-            hipLaunchKernelGGL((gn_stats_kernel<0, true>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
+        SDMI_GN_LAUNCH(gn_stats_fused, lds * rows_h, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
         SDMI_CHECK_LAUNCH();
         return SDMI_OK;
     }
-    if (dtype == SDMI_DTYPE_F16)
-        hipLaunchKernelGGL((gn_stats_kernel<1, false>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
-    else
-        hipLaunchKernelGGL((gn_stats_kernel<0, false>), grid, dim3(GN_THREADS), lds * rows_h, s, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
+    SDMI_GN_LAUNCH(gn_stats_split, lds * rows_h, u1, u2, C1, C2, hw, P, partial, gamma, beta, eps, uo, silu);
     SDMI_CHECK_LAUNCH();
-    if (dtype == SDMI_DTYPE_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(GN_THREADS), lds, s, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
+    SDMI_GN_LAUNCH(gn_apply_kernel, lds, u1, u2, C1, C2, gamma, beta, partial, eps, uo, hw, P, silu);
     SDMI_CHECK_LAUNCH();
+#undef SDMI_GN_LAUNCH
     return SDMI_OK;
 }
 
@@ -454,7 +456,7 @@ extern "C" int sdmi_groupnorm_noalloc(const void* x1, const void* x2, int32_t C1
 
 extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows,
                               int32_t C, float eps, int32_t dtype, void* stream) {
-    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
+    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16 && dtype != SDMI_DTYPE_F16_TO_BF16) return SDMI_ERR_BAD_ARG;
     if (x == nullptr || gamma == nullptr || beta == nullptr || out == nullptr) return SDMI_ERR_BAD_ARG;
     if (rows <= 0 || C <= 0) return SDMI_ERR_BAD_ARG;
     if (C % 8 != 0 || C > 64 * LN_MAXV * 8) return SDMI_ERR_ALIGNMENT;
@@ -465,14 +467,12 @@ extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* be
     const int rpw = 64 / lpr;
     int64_t blocks = (rows + 4 * rpw - 1) / (4 * rpw);
     if (blocks > 16384) blocks = 16384;
-    if (dtype == SDMI_DTYPE_F16)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
-                           rows, C, eps, lpr);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const unsigned short*>(x), gamma, beta, reinterpret_cast<unsigned short*>(out),
-                           rows, C, eps, lpr);
+    const unsigned short* xi = reinterpret_cast<const unsigned short*>(x);
+    unsigned short* xo = reinterpret_cast<unsigned short*>(out);
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SDMI_DTYPE_F16)       hipLaunchKernelGGL((layernorm_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, hs, xi, gamma, beta, xo, rows, C, eps, lpr);
+    else if (dtype == SDMI_DTYPE_BF16) hipLaunchKernelGGL((layernorm_kernel<0, 0>), dim3((unsigned)blocks), dim3(256), 0, hs, xi, gamma, beta, xo, rows, C, eps, lpr);
+    else                               hipLaunchKernelGGL((layernorm_kernel<1, 0>), dim3((unsigned)blocks), dim3(256), 0, hs, xi, gamma, beta, xo, rows, C, eps, lpr);
     SDMI_CHECK_LAUNCH();
     return SDMI_OK;
 }

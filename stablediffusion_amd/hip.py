@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDMI_LIB") or os.path.join(_HERE, "csrc", "libsdmi_hip.so")
 
 SDMI_OK = 0
-DTYPE_BF16, DTYPE_F16, DTYPE_F32_PLANES = 0, 1, 2
+DTYPE_BF16, DTYPE_F16, DTYPE_F32_PLANES, DTYPE_F16_TO_BF16 = 0, 1, 2, 3
 
 
 class SdmiError(RuntimeError):
@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("stages", C.c_int32),
         ("algo", C.c_int32),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("out_f16", C.c_int32), ("res_f16", C.c_int32), ("a_f16", C.c_int32),
         ("dup_rows", C.c_int32),
     ]
 

@@ -50,6 +50,17 @@ def release_scratch(device=None, stream=None):
         del _SCRATCH[key]
 
 
+MIXED_BF16_STREAM = True      # False: the bf16 policy stores its residual stream in bf16 as well (rounds 1 - 2; A/B, tests)
+
+
+def stream_dtype(operand_dtype):
+    """Storage type of the residual stream (the tensors carried from block to block: h, the token stream t, the skip
+    connections) under an operand type.  bf16 operands keep it in f16: the same bytes, 11 significant bits instead of 8 -
+    the CPU emulation (tools/precision_study.py) attributes 1.3-1.5x of the bf16 path's error over its format floor to
+    bf16 storage of the stream, none of which is owed to the reference's bf16 policy."""
+    return F16 if (operand_dtype == BF16 and MIXED_BF16_STREAM) else operand_dtype
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -83,7 +94,11 @@ def _round_up(x, m):
 class PackedWeight:
     """bf16 [Npad, Kpad] weight (K contiguous) + fp32 bias in the layout sdmi_gemm expects."""
 
-    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN, split_cp=0):
+    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN, split_cp=0, out_dtype=None):
+        # 16-bit type of the layer's OUTPUT when it differs from the operand type: the bf16 operand policy keeps its
+        # residual stream in f16 (stream_dtype()), so a layer whose output IS the stream (conv_in, the ResBlock convs,
+        # to_out, the feed-forward's second linear, proj_out ...) has bf16 weights and an f16 output
+        self.out_dtype = out_dtype if out_dtype is not None else w.dtype
         self.split_cp = split_cp  # fp32 mode: > 0 = weights hold six bf16 planes of this width per K group (split3)
         self.w = w              # bf16|fp16 [Npad, Kpad]
         self.tile_n = tile_n    # column tile the rows are padded for (128 | 160)
@@ -148,12 +163,12 @@ def _pack_rows(ws, out, code, tile_n):
         off += n
 
 
-def pack_linear(weight, bias=None, dtype=BF16, tile_n=None):
+def pack_linear(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
-    return pack_linear_cat([weight], None if bias is None else [bias], dtype=dtype, tile_n=tile_n)
+    return pack_linear_cat([weight], None if bias is None else [bias], dtype=dtype, tile_n=tile_n, out_dtype=out_dtype)
 
 
-def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None):
+def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=None):
     """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections)."""
     ws = [_src(x.reshape(x.shape[0], -1)) for x in weights]
     n = sum(w.shape[0] for w in ws)
@@ -164,7 +179,8 @@ def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None):
     kp = hip.lib().sdmi_pack_linear_k(k, code)
     out = _pack_alloc(n, kp, tn, tdt, ws[0].device)
     _pack_rows(ws, out, code, tn)
-    return PackedWeight(out, b, n, kp, tile_n=tn, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0)
+    return PackedWeight(out, b, n, kp, tile_n=tn, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
+                        out_dtype=out_dtype if dtype != torch.float32 else None)
 
 
 def pack_geglu(weight, bias, dtype=BF16):
@@ -186,7 +202,7 @@ def pack_geglu(weight, bias, dtype=BF16):
     return PackedWeight(out, bo, inner, kp, geglu=True, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0)
 
 
-def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
+def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None):
     """Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)] with ci padded to a multiple of 8 (fp32 mode: six planes
     of ci padded to 32 inside every tap)."""
     w = _src(weight)
@@ -202,7 +218,8 @@ def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None):
         st = hip.lib().sdmi_pack_conv3x3_host(_p(w), cout, cin, _p(out), code, tn)
     hip.check(st, "sdmi_pack_conv3x3")
     b = _src(bias) if bias is not None else None
-    return PackedWeight(out, b, cout, kp, cin=cin_p, tile_n=tn, split_cp=cin_p // 6 if dtype == torch.float32 else 0)
+    return PackedWeight(out, b, cout, kp, cin=cin_p, tile_n=tn, split_cp=cin_p // 6 if dtype == torch.float32 else 0,
+                        out_dtype=out_dtype if dtype != torch.float32 else None)
 
 
 # ----------------------------------------------------------------------------- GEMM family
@@ -242,7 +259,7 @@ def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False):
     wide_ok: the 256 x 256 x 32 tile (tile_n 256) may be chosen - the weight is padded to 256 rows and the epilogue is
     one it has; _wide_wins decides."""
     nk = k // _BK
-    if wide_ok and _wide_wins(m, n_w, nk, tile_n):
+    if wide_ok and not geglu and _wide_wins(m, n_w, nk, tile_n):      # (GEGLU: the measured rule below, not the model)
         return (256, 1, 3, 256)
     # GEGLU projections with a short K (levels 0 and 1 of the UNet: K = 320 | 640, many row tiles): half as many tiles,
     # i.e. half as many prologues / epilogues, on the 256 x 256 x 32 tile - measured (tools/bench_gemm.py geglu, WIDE=0|1)
@@ -337,6 +354,10 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     a.alpha = alpha
     a.batch = 1
     a.out = out.data_ptr()
+    if out_kind == 0 and out.dtype != pw.dtype:
+        if not (pw.dtype == BF16 and out.dtype == F16):
+            raise hip.SdmiError(f"16-bit output {out.dtype} under {pw.dtype} operands")
+        a.out_f16 = 1
     if out_kind == 2:
         a.ld_out = 0
     else:
@@ -349,7 +370,11 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.emb = emb.data_ptr()
         a.ld_emb = emb.stride(0)
     if res is not None:
-        _require(res, torch.float32 if pw.split_cp else pw.dtype, "res")
+        if not pw.split_cp and pw.dtype == BF16 and res.dtype == F16:
+            _require(res, F16, "res")            # the f16 residual stream of the bf16 operand policy
+            a.res_f16 = 1
+        else:
+            _require(res, torch.float32 if pw.split_cp else pw.dtype, "res")
         a.res_f32 = 1 if pw.split_cp else 0
         a.res = res.data_ptr()
         a.ld_res = res.shape[-1]
@@ -402,13 +427,14 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     if dup_rows and (pw.split_cp or out_nchw_f32 is not None or (out_dtype is not None and out_dtype not in HALF_TYPES)):
         raise hip.SdmiError("linear: dup_rows needs a 16-bit row-major output")
     if ln is not None and (pw.split_cp or x2 is not None or not FUSE_LN):
-        x, ln = layernorm(x, *ln), None
+        x, ln = layernorm(x, *ln, out_dtype=None if pw.split_cp else pw.dtype), None
     if pw.split_cp:
         x = split3(x, pw.split_cp, x2)
         x2 = None
         out_dtype = torch.float32
-    _require(x, pw.dtype, "x")
-    out_dtype = out_dtype or pw.dtype
+    stream_in = ln is not None and not pw.split_cp and pw.dtype == BF16 and x.dtype == F16
+    _require(x, F16 if stream_in else pw.dtype, "x")      # (stream_in: the LayerNorm turns the f16 stream into the bf16 operand)
+    out_dtype = out_dtype or pw.out_dtype
     k1 = x.shape[-1]
     m = x.numel() // k1
     a = hip.GemmArgs()
@@ -446,10 +472,11 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
             raise hip.SdmiError("linear: LayerNorm parameters do not match K")
         if hip.lib().sdmi_gemm_panel_applies(C.byref(a)):
             a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), ln[2] if len(ln) > 2 else 1e-5
+            a.a_f16 = 1 if stream_in else 0
             if a.tile_n == 256:       # the plan's 256 x 256 x 32 tile gives way to the kernel that carries the LayerNorm
                 a.tile_n, a.tile_m = pw.tile_n, 0
         else:
-            xn = layernorm(x, *ln)
+            xn = layernorm(x, *ln, out_dtype=pw.dtype)
             a.A = xn.data_ptr()
     _run_gemm(a, "sdmi_gemm(linear)")
     del keep
@@ -482,11 +509,11 @@ def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=Fa
         if out_nchw_f32 or pw.split_cp:
             raise hip.SdmiError("conv3x3: dup_rows needs a 16-bit NHWC output")
         a.dup_rows = 1
-        out = torch.empty(2 * b, ho, wo, pw.n_out, dtype=pw.dtype, device=x.device)
+        out = torch.empty(2 * b, ho, wo, pw.n_out, dtype=pw.out_dtype, device=x.device)
     elif out_nchw_f32:
         out = torch.empty(b, pw.n_out, ho, wo, dtype=torch.float32, device=x.device)
     else:
-        out = torch.empty(b, ho, wo, pw.n_out, dtype=torch.float32 if pw.split_cp else pw.dtype, device=x.device)
+        out = torch.empty(b, ho, wo, pw.n_out, dtype=torch.float32 if pw.split_cp else pw.out_dtype, device=x.device)
     keep = _fill_common(a, pw, out, True, emb, ho * wo, res, 0, 2 if out_nchw_f32 else (1 if pw.split_cp else 0), 1.0, m)
     _run_gemm(a, "sdmi_gemm(conv3x3)")
     del keep
@@ -530,9 +557,19 @@ def gemm_nt_batched(a_mat, b_mat, out_dtype, alpha=1.0, bias_rows=None):
 # ----------------------------------------------------------------------------- norms
 
 
-def groupnorm(x1, gamma, beta, eps, silu, x2=None):
+def _norm_dt(in_dtype, out_dtype):
+    """sdmi_dtype code of a norm kernel for (input, output) types: same type, or f16 stream -> bf16 operand."""
+    if out_dtype is None or out_dtype == in_dtype:
+        return _dt(in_dtype)
+    if in_dtype == F16 and out_dtype == BF16:
+        return hip.DTYPE_F16_TO_BF16
+    raise hip.SdmiError(f"norm kernels convert f16 -> bf16 only, not {in_dtype} -> {out_dtype}")
+
+
+def groupnorm(x1, gamma, beta, eps, silu, x2=None, out_dtype=None):
     """GroupNorm(32)(+SiLU) over NHWC 16-bit (or fp32 in fp32 mode); x2 = second half of a channel concat (read in
-    place)."""
+    place).  out_dtype: the operand type of the consuming GEMM when it differs from the input's (bf16 policy: the input
+    is the f16 residual stream, the output a bf16 operand)."""
     if x1.dtype == torch.float32:
         _require(x1, torch.float32, "x1")
         _require(x2, torch.float32, "x2")
@@ -542,7 +579,7 @@ def groupnorm(x1, gamma, beta, eps, silu, x2=None):
         hip.check(hip.lib().sdmi_f32_groupnorm(_p(x1), _p(x2), c1, c2, _p(gamma), _p(beta), _p(out), b,
                                                x1.numel() // (b * c1), eps, 1 if silu else 0, _stream()), "sdmi_f32_groupnorm")
         return out
-    dt = _dt(x1.dtype)
+    dt = _norm_dt(x1.dtype, out_dtype)
     _require(x1, x1.dtype, "x1")
     _require(x2, x1.dtype, "x2")
     _require(gamma, torch.float32, "gamma")
@@ -551,7 +588,7 @@ def groupnorm(x1, gamma, beta, eps, silu, x2=None):
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
     hw = x1.numel() // (b * c1)
-    out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=x1.dtype, device=x1.device)
+    out = torch.empty(*x1.shape[:-1], c1 + c2, dtype=out_dtype or x1.dtype, device=x1.device)
     nbytes = hip.lib().sdmi_groupnorm_workspace_bytes(b, hw)
     ws = _scratch(nbytes, x1.device)
     _traced("groupnorm", 2 * out.numel() * out.element_size(), (b, hw, c1 + c2),
@@ -560,7 +597,7 @@ def groupnorm(x1, gamma, beta, eps, silu, x2=None):
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
     if x.dtype == torch.float32:
         _require(x, torch.float32, "x")
         out = torch.empty_like(x)
@@ -568,10 +605,10 @@ def layernorm(x, gamma, beta, eps=1e-5):
         hip.check(hip.lib().sdmi_f32_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, _stream()),
                   "sdmi_f32_layernorm")
         return out
-    dt = _dt(x.dtype)
+    dt = _norm_dt(x.dtype, out_dtype)
     _require(x, x.dtype, "x")
     c = x.shape[-1]
-    out = torch.empty_like(x)
+    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     _traced("layernorm", 2 * out.numel() * out.element_size(), (x.numel() // c, c),
             lambda: hip.check(hip.lib().sdmi_layernorm(_p(x), _p(gamma), _p(beta), _p(out), x.numel() // c, c, eps, dt,
                                                        _stream()), "sdmi_layernorm"))

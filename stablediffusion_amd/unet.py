@@ -135,9 +135,11 @@ def pack_spatial_transformer(st, cd, kv_off=0):
     in that concatenation.  project_in / proj_out may be nn.Linear (use_linear=True) or 1x1 nn.Conv2d (attention.py:213-226):
     on NHWC activations both are the same [C_out, C_in] GEMM."""
     f32 = lambda t: t.detach().float().contiguous()
+    sd = ops.stream_dtype(cd) if cd in ops.HALF_TYPES else None      # the outputs that ARE the residual stream (t, h)
     e = {"norm": (f32(st.norm.weight), f32(st.norm.bias)),
-         "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias, dtype=cd),
-         "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias, dtype=cd), "blocks": []}
+         "pin": ops.pack_linear(st.project_in.weight, st.project_in.bias, dtype=cd, out_dtype=sd),
+         # proj_out reads the token stream itself (attention.py:257-262: no norm in front of it): a stream-typed layer
+         "pout": ops.pack_linear(st.proj_out.weight, st.proj_out.bias, dtype=sd or cd), "blocks": []}
     kv_w = []
     for tb in st.transformer_blocks:
         c = tb.attn1.to_q.weight.shape[0]
@@ -146,11 +148,11 @@ def pack_spatial_transformer(st, cd, kv_off=0):
             "ln2": (f32(tb.norm2.weight), f32(tb.norm2.bias)),
             "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
             "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd),
-            "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd),
+            "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd, out_dtype=sd),
             "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd),
-            "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd),
+            "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd, out_dtype=sd),
             "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd),
-            "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd),
+            "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd, out_dtype=sd),
             "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
         }
         if tb.attn1.dim_head != 64:
@@ -175,7 +177,7 @@ def run_spatial_transformer(e, h, kv, nk, pair_prefix=False):
         # produced it: ops.conv3x3(dup_rows=True)); what precedes the first cross-attention works on the first half
         b //= 2
         h = h[:b]
-    xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False)
+    xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False, out_dtype=e["pin"].dtype)
     t = ops.linear(xn.reshape(b * n, c), e["pin"])
     for bi, be in enumerate(e["blocks"]):
         ci, heads = be["c"], be["heads"]
@@ -369,6 +371,11 @@ class UNetModel(nn.Module):
             raise NotImplementedError(f"HIP UNetModel: unsupported compute dtype {cd}")
         pk = {}
         f32 = lambda t: t.detach().float().contiguous()
+        # residual-stream storage (h, the skips, the token stream): the operand type, except that bf16 operands keep it
+        # in f16 (ops.stream_dtype).  Layers whose OUTPUT is the stream get out_dtype=sd; the few whose INPUT is the raw
+        # stream (DownSample / UpSample convs, the 1x1 skip_connection) are packed in the stream type and run as GEMMs
+        # of that type - under the bf16 policy they are f16 layers.
+        sd = ops.stream_dtype(cd) if cd in ops.HALF_TYPES else None
         te = self.time_embedding
         pk["te0"] = ops.pack_linear(te[0].weight, te[0].bias, dtype=cd)
         pk["te2"] = ops.pack_linear(te[2].weight, te[2].bias, dtype=cd)
@@ -381,13 +388,13 @@ class UNetModel(nn.Module):
             e = {"emb_off": off}
             off += r.out_channels
             e["gn1"] = (f32(r.in_layers[0].weight), f32(r.in_layers[0].bias))
-            e["conv1"] = ops.pack_conv3x3(r.in_layers[2].weight, r.in_layers[2].bias, dtype=cd)
+            e["conv1"] = ops.pack_conv3x3(r.in_layers[2].weight, r.in_layers[2].bias, dtype=cd, out_dtype=sd)
             e["gn2"] = (f32(r.out_layers[0].weight), f32(r.out_layers[0].bias))
-            e["conv2"] = ops.pack_conv3x3(r.out_layers[3].weight, r.out_layers[3].bias, dtype=cd)
+            e["conv2"] = ops.pack_conv3x3(r.out_layers[3].weight, r.out_layers[3].bias, dtype=cd, out_dtype=sd)
             if isinstance(r.skip_connection, nn.Conv2d):
                 if r.skip_connection.kernel_size != (1, 1):
                     raise NotImplementedError("3x3 skip_connection (use_conv=True) is outside the SD2 path")
-                e["skip"] = ops.pack_linear(r.skip_connection.weight, r.skip_connection.bias, dtype=cd)
+                e["skip"] = ops.pack_linear(r.skip_connection.weight, r.skip_connection.bias, dtype=sd or cd)
             pk[id(r)] = e
         # cross-attention K/V of every transformer block, one GEMM on the context
         kv_w = []
@@ -398,12 +405,12 @@ class UNetModel(nn.Module):
         pk["kv_all"] = ops.pack_linear_cat(kv_w, dtype=cd)
         for blk in list(self.input_blocks) + list(self.output_blocks):
             for layer in blk:
-                if isinstance(layer, nn.Conv2d):
-                    pk[id(layer)] = ops.pack_conv3x3(layer.weight, layer.bias, dtype=cd)
+                if isinstance(layer, nn.Conv2d):          # conv_in: operand = the converted latents, output = the stream
+                    pk[id(layer)] = ops.pack_conv3x3(layer.weight, layer.bias, dtype=cd, out_dtype=sd)
                 elif isinstance(layer, DownSample):
-                    pk[id(layer)] = ops.pack_conv3x3(layer.operation.weight, layer.operation.bias, dtype=cd)
+                    pk[id(layer)] = ops.pack_conv3x3(layer.operation.weight, layer.operation.bias, dtype=sd or cd)
                 elif isinstance(layer, UpSample):
-                    pk[id(layer)] = ops.pack_conv3x3(layer.conv.weight, layer.conv.bias, dtype=cd)
+                    pk[id(layer)] = ops.pack_conv3x3(layer.conv.weight, layer.conv.bias, dtype=sd or cd)
         pk["out_gn"] = (f32(self.out[0].weight), f32(self.out[0].bias))
         pk["out_conv"] = ops.pack_conv3x3(self.out[2].weight, self.out[2].bias, dtype=cd)
         self._pack = pk
@@ -424,9 +431,9 @@ class UNetModel(nn.Module):
     def _res_block(self, pk, r, h, skip, emb_all, dup_rows=False):
         e = pk[id(r)]
         emb = emb_all[:, e["emb_off"]:e["emb_off"] + r.out_channels]
-        n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-5, True, x2=skip)
+        n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-5, True, x2=skip, out_dtype=e["conv1"].dtype)
         h1 = ops.conv3x3(n1, e["conv1"], emb=emb)
-        n2 = ops.groupnorm(h1, e["gn2"][0], e["gn2"][1], 1e-5, True)
+        n2 = ops.groupnorm(h1, e["gn2"][0], e["gn2"][1], 1e-5, True, out_dtype=e["conv2"].dtype)
         if "skip" in e:
             sk = ops.linear(h, e["skip"], x2=skip)
         else:
@@ -558,6 +565,6 @@ class UNetModel(nn.Module):
         h = self._run_block(pk, self.middle_block, h, None, emb_all, kv, nk)
         for blk in self.output_blocks:
             h = self._run_block(pk, blk, h, hs.pop(), emb_all, kv, nk)
-        n = ops.groupnorm(h, pk["out_gn"][0], pk["out_gn"][1], 1e-5, True)
+        n = ops.groupnorm(h, pk["out_gn"][0], pk["out_gn"][1], 1e-5, True, out_dtype=pk["out_conv"].dtype)
         out = ops.conv3x3(n, pk["out_conv"], out_nchw_f32=True)
         return out.type(x.dtype)

@@ -94,23 +94,28 @@ class _VaeNet(nn.Module):
         f32 = lambda t: t.detach().float().contiguous()
         pk = {}
         cd = self.compute_dtype
+        # residual-stream storage (ops.stream_dtype: f16 under bf16 operands): layers whose output is the stream get
+        # out_dtype=sd, layers whose INPUT is the raw stream (nin_shortcut, the Up / DownSample convs) run in the stream type
+        sd = ops.stream_dtype(cd) if cd in ops.HALF_TYPES else None
         for m in self.modules():
             if isinstance(m, ResnetBlock):
-                e = {"gn1": (f32(m.norm1.weight), f32(m.norm1.bias)), "conv1": ops.pack_conv3x3(m.conv1.weight, m.conv1.bias, dtype=cd),
-                     "gn2": (f32(m.norm2.weight), f32(m.norm2.bias)), "conv2": ops.pack_conv3x3(m.conv2.weight, m.conv2.bias, dtype=cd)}
+                e = {"gn1": (f32(m.norm1.weight), f32(m.norm1.bias)),
+                     "conv1": ops.pack_conv3x3(m.conv1.weight, m.conv1.bias, dtype=cd, out_dtype=sd),
+                     "gn2": (f32(m.norm2.weight), f32(m.norm2.bias)),
+                     "conv2": ops.pack_conv3x3(m.conv2.weight, m.conv2.bias, dtype=cd, out_dtype=sd)}
                 if hasattr(m, "nin_shortcut"):
-                    e["skip"] = ops.pack_linear(m.nin_shortcut.weight, m.nin_shortcut.bias, dtype=cd)
+                    e["skip"] = ops.pack_linear(m.nin_shortcut.weight, m.nin_shortcut.bias, dtype=sd or cd)
                 pk[id(m)] = e
             elif isinstance(m, AttnBlock):
                 c = m.in_channels
                 pk[id(m)] = {
                     "gn": (f32(m.norm.weight), f32(m.norm.bias)),
                     "qkv": ops.pack_linear_cat([m.q.weight, m.k.weight, m.v.weight], [m.q.bias, m.k.bias, m.v.bias], dtype=cd),
-                    "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias, dtype=cd),
+                    "proj": ops.pack_linear(m.proj_out.weight, m.proj_out.bias, dtype=cd, out_dtype=sd),
                 }
             elif isinstance(m, (UpSample, DownSample)):
-                pk[id(m)] = ops.pack_conv3x3(m.conv.weight, m.conv.bias, dtype=cd)
-        pk["conv_in"] = ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, dtype=cd)
+                pk[id(m)] = ops.pack_conv3x3(m.conv.weight, m.conv.bias, dtype=sd or cd)
+        pk["conv_in"] = ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, dtype=cd, out_dtype=sd)
         pk["norm_out"] = (f32(self.norm_out.weight), f32(self.norm_out.bias))
         pk["conv_out"] = ops.pack_conv3x3(self.conv_out.weight, self.conv_out.bias, dtype=cd)
         self._pack = pk
@@ -118,9 +123,9 @@ class _VaeNet(nn.Module):
 
     def _resnet(self, pk, m, h):
         e = pk[id(m)]
-        n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-6, True)
+        n1 = ops.groupnorm(h, e["gn1"][0], e["gn1"][1], 1e-6, True, out_dtype=e["conv1"].dtype)
         h1 = ops.conv3x3(n1, e["conv1"])
-        n2 = ops.groupnorm(h1, e["gn2"][0], e["gn2"][1], 1e-6, True)
+        n2 = ops.groupnorm(h1, e["gn2"][0], e["gn2"][1], 1e-6, True, out_dtype=e["conv2"].dtype)
         sk = ops.linear(h, e["skip"]) if "skip" in e else h
         return ops.conv3x3(n2, e["conv2"], res=sk)
 
@@ -134,7 +139,7 @@ class _VaeNet(nn.Module):
             raise ValueError(f"vae_attn must be 'reference' or 'standard', got {self.vae_attn!r}")
         if c not in (64, 128, 256, 512) or (n % 2 and self.compute_dtype != torch.float32):
             raise NotImplementedError("VAE attention is built for 64 / 128 / 256 / 512 channels and an even token count")
-        hn = ops.groupnorm(h, e["gn"][0], e["gn"][1], 1e-6, False).reshape(b * n, c)
+        hn = ops.groupnorm(h, e["gn"][0], e["gn"][1], 1e-6, False, out_dtype=e["qkv"].dtype).reshape(b * n, c)
         qkv = ops.linear(hn, e["qkv"])
         o = ops.attention_vae(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], b, n, float(int(c) ** (-0.5)), self.vae_attn)
         out = ops.linear(o, e["proj"], res=h.reshape(b * n, c))
@@ -206,7 +211,7 @@ class Encoder(_VaeNet):
         h = self._resnet(pk, self.mid.block_1, h)
         h = self._attn(pk, self.mid.attn_1, h)
         h = self._resnet(pk, self.mid.block_2, h)
-        n = ops.groupnorm(h, pk["norm_out"][0], pk["norm_out"][1], 1e-6, True)
+        n = ops.groupnorm(h, pk["norm_out"][0], pk["norm_out"][1], 1e-6, True, out_dtype=pk["conv_out"].dtype)
         return ops.conv3x3(n, pk["conv_out"])
 
 
@@ -296,7 +301,7 @@ class Decoder(_VaeNet):
                     h = self._attn(pk, lvl.attn[i_block], h)
             if i_level != 0:
                 h = ops.conv3x3(h, pk[id(lvl.up_sample)], upsample=True)
-        n = ops.groupnorm(h, pk["norm_out"][0], pk["norm_out"][1], 1e-6, True)
+        n = ops.groupnorm(h, pk["norm_out"][0], pk["norm_out"][1], 1e-6, True, out_dtype=pk["conv_out"].dtype)
         return ops.conv3x3(n, pk["conv_out"], out_nchw_f32=True)
 
 

@@ -454,6 +454,68 @@ def test_dup_rows_store_is_a_bit_exact_copy(dev, dt, monkeypatch):
         ops.conv3x3(rnd((1, 16, 16, 64), dev, 22).to(dt), pn, dup_rows=True)
 
 
+def test_bf16_operands_with_f16_residual_stream(dev):
+    """The bf16 operand policy's f16 residual stream (sdmi_gemm_args.out_f16 / res_f16 / a_f16, SDMI_DTYPE_F16_TO_BF16):
+    bf16 x bf16 GEMMs / convs that add an f16 residual and store f16, norms that read f16 and write the bf16 operand, the
+    panel kernel whose fused LayerNorm reads the f16 stream - each against the fp32 formula on the rounded inputs, to the
+    rounding of its OUTPUT type (f16: 2^-11, bf16: 2^-8 relative); and the refusals."""
+    ops = _ops()
+    from stablediffusion_amd import hip
+    qb = lambda t: t.to(BF16).float()
+    qh = lambda t: t.to(F16).float()
+    # linear: tiled kernel (fast epilogue, the 4-column path, split-K reduce) and an N the fast path does not take
+    for m, n, k in ((4096, 320, 320), (300, 324, 192), (256, 1280, 5120)):
+        x, w, b, res = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3), rnd((m, n), dev, 4)
+        pw = ops.pack_linear(w, b, dtype=BF16, out_dtype=F16)
+        out = ops.linear(x.to(BF16), pw, res=res.to(F16))
+        assert out.dtype == F16
+        assert rel_err(out, F.linear(qb(x), qb(w), b) + qh(res)) < 1.5e-3, (m, n, k)
+    # conv3x3 with embedding + f16 residual -> f16
+    xi, wc, bc = rnd((2, 24, 24, 64), dev, 5), rnd((96, 64, 3, 3), dev, 6, 576 ** -0.5), rnd((96,), dev, 7)
+    emb, res = rnd((2, 96), dev, 8), rnd((2, 24, 24, 96), dev, 9)
+    pc = ops.pack_conv3x3(wc, bc, dtype=BF16, out_dtype=F16)
+    out = ops.conv3x3(xi.to(BF16), pc, emb=emb, res=res.to(F16))
+    ref = F.conv2d(qb(xi).permute(0, 3, 1, 2), qb(wc), bc, padding=1) + emb[:, :, None, None] + qh(res).permute(0, 3, 1, 2)
+    assert out.dtype == F16 and rel_err(out.permute(0, 3, 1, 2), ref) < 1.5e-3
+    # norms: f16 in -> bf16 out
+    xs = (rnd((2, 40, 40, 320), dev, 10) * 1.5 + 0.3).to(F16)
+    g, bta = 1 + 0.1 * rnd((320,), dev, 11), 0.1 * rnd((320,), dev, 12)
+    for fused_hw in (xs, xs[:, :8]):               # two-launch and fused single-launch forms
+        y = ops.groupnorm(fused_hw.contiguous(), g, bta, 1e-5, True, out_dtype=BF16)
+        xf = fused_hw.float()
+        nb_, hh_, ww_, c_ = xf.shape
+        v = xf.reshape(nb_, hh_ * ww_, 32, c_ // 32)
+        mu, var = v.mean(dim=(1, 3), keepdim=True), v.var(dim=(1, 3), unbiased=False, keepdim=True)
+        yr = ((v - mu) * torch.rsqrt(var + 1e-5)).reshape(xf.shape) * g + bta
+        assert y.dtype == BF16 and rel_err(y, F.silu(yr)) < 6e-3
+    t = (rnd((1000, 640), dev, 13) * 2 + 0.5).to(F16)
+    g, bta = 1 + 0.1 * rnd((640,), dev, 14), 0.1 * rnd((640,), dev, 15)
+    y = ops.layernorm(t, g, bta, out_dtype=BF16)
+    assert y.dtype == BF16 and rel_err(y, F.layer_norm(t.float(), (640,), g, bta)) < 6e-3
+    # the panel kernel: LayerNorm of the f16 stream fused into a bf16 projection == separate launches, to bf16 rounding
+    m = 16384
+    t = (rnd((m, 320), dev, 16) * 2 + 0.5).to(F16)
+    g, bta = 1 + 0.1 * rnd((320,), dev, 17), 0.1 * rnd((320,), dev, 18)
+    w = rnd((960, 320), dev, 19, 320 ** -0.5)
+    pw = ops.pack_linear(w, None, dtype=BF16)
+    fused = ops.linear(t, pw, ln=(g, bta))
+    ref = F.linear(qb(F.layer_norm(t.float(), (320,), g, bta)), qb(w))
+    assert fused.dtype == BF16 and rel_err(fused, ref) < 8e-3
+    # refusals: the flags are a bf16-operand matter; a GEGLU output is never the stream; a_f16 needs the LayerNorm
+    a = hip.GemmArgs()
+    x16 = torch.zeros(256, 320, dtype=F16, device=dev)
+    o16 = torch.zeros(256, 320, dtype=F16, device=dev)
+    pw16 = ops.pack_linear(rnd((320, 320), dev, 20), None, dtype=F16)
+    a.mode, a.A, a.lda, a.M, a.N, a.K, a.W, a.out, a.ld_out = 0, x16.data_ptr(), 320, 256, 320, 320, pw16.w.data_ptr(), o16.data_ptr(), 320
+    a.dtype, a.alpha, a.tile_n, a.batch, a.split_k, a.out_f16 = hip.DTYPE_F16, 1.0, 160, 1, 1, 1
+    assert hip.lib().sdmi_gemm(C.byref(a), None) == -1
+    a.dtype, a.out_f16, a.a_f16 = hip.DTYPE_BF16, 0, 1
+    assert hip.lib().sdmi_gemm(C.byref(a), None) == -1
+    with pytest.raises(hip.SdmiError):
+        ops.groupnorm(xs.to(BF16), g[:320], bta[:320], 1e-5, True, out_dtype=F16)      # bf16 -> f16 does not exist
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("b,hw,c1,c2,silu,eps", [
     (2, 1024, 320, 0, True, 1e-5), (2, 256, 640, 320, True, 1e-5), (1, 64, 1280, 1280, True, 1e-5),
     (2, 4096, 128, 0, True, 1e-6), (1, 100, 1280, 640, False, 1e-6), (3, 70000, 128, 0, True, 1e-6),

@@ -6,13 +6,16 @@ Gates (BASELINE.json north_star):  relative error = max|a-b| /
   * decoded image PSNR          >= 35 dB
 
 The benchmarked (headline) dtype is **fp16** - the operand type the reference's own v2-inference.yaml:24 selects
-(use_fp16: True) - and every fp16 case below is asserted at NORTH_STAR = 1e-2 (measured 1.3-2.7e-3).
-bf16 operands (use_bf16) run at the same MFMA rate and are kept as the secondary policy.  They are asserted at
-BF16_DOCUMENTED = 2.1e-2 (1.2 x the measured worst case), NOT at the north-star figure: rounding ONLY the two operands of every contraction to bf16
-(oracle.model.operand_precision - what an ideal bf16 MFMA with fp32 accumulators computes) already costs 0.8-1.4e-2
-against fp32 on these networks, and keeping the residual stream in bf16 as well (oracle.model.storage_precision - what
-this path does) costs 1.07-1.46e-2 in the CPU emulation (tools/precision_study.py, both weight recipes).
-8 significant bits cannot meet 1e-2 on every input; 11 bits (fp16) do, with a 4-8x margin.
+(use_fp16: True) - and every fp16 case below is asserted at NORTH_STAR = 1e-2 (measured 1.2-2.4e-3).
+bf16 operands (use_bf16) run at the same MFMA rate and are kept as the secondary policy.  Since round 3 the bf16 policy
+keeps its RESIDUAL STREAM in f16 (ops.stream_dtype: same bytes, 11 significant bits; only the MFMA operands - weights,
+norm outputs, q/k/v, the GEGLU product - carry bf16 rounding, and the few layers that read the raw stream run as f16
+layers): every per-step bf16 case of this file now measures <= 1e-2 against the fp32 oracle / the reference's goldens
+(4.8e-3 ... 9.8e-3; rounds 1-2 with a bf16 stream: 0.9-1.8e-2), i.e. bf16 meets the north-star figure as well.  Its gate
+is BF16_DOCUMENTED = 1.2e-2 = 1.2 x the worst measured case (teacher-forced v-prediction DDIM step, 9.83e-3) rather than
+1e-2 itself, because that worst case sits 2 % under the figure and 8-bit operand rounding is input dependent: rounding
+ONLY the two operands of every contraction to bf16 (oracle.model.operand_precision - an ideal bf16 MFMA with fp32
+accumulators and an fp32 stream) costs 0.8-1.4e-2 on these networks (tools/precision_study.py).
 Every measured number is printed as a [parity] line.
 """
 import math
@@ -27,9 +30,8 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 NORTH_STAR = 1e-2
-BF16_DOCUMENTED = 2.1e-2      # secondary dtype only - see the module docstring; never applied to the headline dtype.
-                              # = 1.2 x the worst bf16 figure measured over all cases of this file (1.75e-2: teacher-forced
-                              # v-prediction DDIM step; the others 0.88-1.63e-2), not a round number with slack
+BF16_DOCUMENTED = 1.2e-2      # secondary dtype only - see the module docstring; never applied to the headline dtype.
+                              # = 1.2 x the worst bf16 per-step figure measured over all cases of this file (9.83e-3)
 HEADLINE = "fp16"             # the dtype bench.py reports
 BF16 = torch.bfloat16
 
@@ -115,7 +117,7 @@ def test_cfg_pairs_prefix_equals_full_batch(dev, dt):
     pairs = m(x_in, t_in, ctx.to(dev), cfg_pairs=True)
     e = rel_err(pairs, full)
     print(f"[parity] sd2 unet h64 cfg_pairs vs full batch ({dt}): rel_err {e:.3e}")
-    assert e < (4e-3 if dt == "fp16" else 2.5e-2)
+    assert e < (4e-3 if dt == "fp16" else 1.2e-2)
     with torch.no_grad():
         ref = OM.unet_forward(sd, synth.SD2_UNET, z[1:], t[1:], ctx[3:])       # row 3 = (z[1], t[1], ctx[3])
     e_full, e_pairs = rel_err(full[3:], ref), rel_err(pairs[3:], ref)
