@@ -417,9 +417,12 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin + c_ci;                      \
         SDMI_GLDS(ok_ ? A + off_ : zsrc, D0, 8192 * (I));                                                  \
     } while (0)
+#ifndef SDMI_DEBUG_CENTER_TAP
+#define SDMI_DEBUG_CENTER_TAP 0   // timing experiment only (results wrong): every tap reads the centre tap's pixels, i.e. perfect L2 reuse of A
+#endif
 #define SDMI_TAP_PTR(I, KY, KX)                                                                            \
     do {                                                                                                   \
-        int iy_ = iy0[I] + (KY), ix_ = ix0[I] + (KX);                                                      \
+        int iy_ = iy0[I] + (SDMI_DEBUG_CENTER_TAP ? 1 : (KY)), ix_ = ix0[I] + (SDMI_DEBUG_CENTER_TAP ? 1 : (KX)); \
         const bool ok_ = (unsigned)iy_ < (unsigned)Hl && (unsigned)ix_ < (unsigned)Wl;                     \
         iy_ >>= p.upsample; ix_ >>= p.upsample;                                                            \
         const int64_t off_ = (a_off[I] + (int64_t)iy_ * p.W_in + ix_) * p.Cin;                             \

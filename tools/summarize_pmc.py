@@ -52,7 +52,7 @@ for r in csv.DictReader(open(sys.argv[3])):
         dur[f][0] += int(r["Calls"])
         dur[f][1] += float(r["TotalDurationNs"])
 res = {"note": "L2-miss bytes per launch from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
-               "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 --no-secondary` (end of round 2, r02d: + 256 x 256 x 32 tile, hoisted residual loads, packed GELU, row-coalesced attention stores); FETCH_SIZE doubled "
+               "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch1 --no-secondary --no-legs` (round 3: hoisted time path, dup_rows prefix, GEGLU on the 256 x 256 x 32 tile at K <= 640, GroupNorm butterfly reduction); FETCH_SIZE doubled "
                "per MI355X_MICROARCH.md; Infinity-Cache hits included (an upper bound on HBM bytes)",
        "unit_note": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); average "
                     "durations from the --kernel-trace --stats run of the same build",
