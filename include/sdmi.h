@@ -45,7 +45,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 12: + sdmi_gemm_args.ln_colsum (LayerNorm folded into the projection); 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -131,6 +131,18 @@ typedef struct sdmi_gemm_args {
                                            with the 16-bit row-major fast epilogue (out_kind 0, no GEGLU, N % 8 == 0, column
                                            bias, ld_out % 8 == 0, ld_res % 8 == 0, 16-byte aligned out / res), batch 1,
                                            split_k 1 and N > 16 - SDMI_ERR_BAD_ARG otherwise */
+    /* ln_colsum non-NULL: the nn.LayerNorm in front of the projection (attention.py:512-514, 528-541) FOLDED into it - no
+       normalised copy of A exists at any point.  With W' = W * gamma[k] (the caller packs W', rounded to f16) and
+           colsum[n] = sum_k W'[n, k]   (of the rounded values, in packed weight-row order: the GEGLU interleave included),
+           bias'[n]  = bias[n] + sum_k beta[k] * W[n, k]   (passed as `bias`),
+       LayerNorm(a) @ W^T + bias = rstd[m] * (a @ W'^T - mean[m] * colsum[n]) + bias'[n]: the kernel multiplies the RAW rows
+       of A, gathers sum(a) and sum(a^2) of every row from the operand fragments it already holds (biased variance, fp32,
+       eps = ln_eps) and applies the two per-row numbers to the accumulators in front of the usual epilogue.  With split_k
+       > 1 the per-slice row sums travel in the workspace behind the slabs (sdmi_gemm_workspace_bytes counts them) and the
+       reduce pass applies them.  dtype SDMI_DTYPE_F16, mode 0, no A2, no emb, batch 1, N_w % 4 == 0, stages != 2, algo != 2,
+       ln_gamma NULL - SDMI_ERR_BAD_ARG otherwise.  `colsum` holds one float per PACKED weight row (N_w rounded up to the
+       tile the weight was packed for, 0 for the padding rows: what summing the packed buffer's rows gives). */
+    const float* ln_colsum;
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);

@@ -40,6 +40,19 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
             v += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol);
             if (p.geglu) g += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol + 16);
         }
+        if (p.ln_colsum != nullptr) {
+            // LayerNorm folded into the projection: the slices' row sums sit behind the slabs ([split][M][2])
+            const float* st = ws + p.split_k * slab;
+            float s1 = 0.f, s2 = 0.f;
+            for (int s = 0; s < p.split_k; ++s) {
+                s1 += st[(s * p.M + m) * 2];
+                s2 += st[(s * p.M + m) * 2 + 1];
+            }
+            float mean, rstd;
+            lnf_mean_rstd(s1, s2, 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K), p.ln_eps, mean, rstd);
+            v = (v - mean * *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol)) * rstd;
+            if (p.geglu) g = (g - mean * *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol + 16)) * rstd;
+        }
         v *= p.alpha;
         int64_t n = wcol;
         if (p.geglu) {
@@ -72,6 +85,10 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
 SDMI_GEMM_UNIT_DECL(m0_bf16) SDMI_GEMM_UNIT_DECL(m0_f16) SDMI_GEMM_UNIT_DECL(m1_bf16) SDMI_GEMM_UNIT_DECL(m1_f16)
 #undef SDMI_GEMM_UNIT_DECL
 
+int sdmi_gemm_unit_attrs_m0_f16_lnf();                                   // sdmi_gemm_lnf.hip (LayerNorm folded, mode 0, f16)
+void sdmi_gemm_unit_launch_m0_f16_lnf(int wide, int variant, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+int sdmi_gemm_wide_attrs_f16_lnf();
+void sdmi_gemm_wide_launch_f16_lnf(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_wide_attrs_bf16();                                         // sdmi_gemm_wide_*.hip
 int sdmi_gemm_wide_attrs_f16();
 void sdmi_gemm_wide_launch_bf16(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
@@ -95,7 +112,8 @@ extern "C" int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t spl
     // enough for any column tile (128, 160 or 256)
     int64_t ldw = slab_ld(N_w, 128) > slab_ld(N_w, 160) ? slab_ld(N_w, 128) : slab_ld(N_w, 160);
     if (slab_ld(N_w, 256) > ldw) ldw = slab_ld(N_w, 256);
-    return (int64_t)split_k * M * ldw * (int64_t)sizeof(float);
+    // (+ the per-slice row sums of a LayerNorm-folded launch, ln_colsum: [split][M][2])
+    return (int64_t)split_k * M * (ldw + 2) * (int64_t)sizeof(float);
 }
 
 // The 256 x 256 x 32 tile (sdmi_gemm_wide.h) runs whole k-tiles from plain row / tap pointers and has two epilogues: the
@@ -179,7 +197,8 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
     if (split > 1) {
         if (split > p.K / BK) return SDMI_ERR_BAD_ARG;
-        if (p.workspace == nullptr || p.workspace_bytes < (int64_t)split * p.M * slab_ld(n_w, BN) * (int64_t)sizeof(float))
+        const int64_t row_floats = slab_ld(n_w, BN) + (p.ln_colsum != nullptr ? 2 : 0);
+        if (p.workspace == nullptr || p.workspace_bytes < (int64_t)split * p.M * row_floats * (int64_t)sizeof(float))
             return SDMI_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -198,6 +217,12 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         if (p.dup_rows != 1 || batch > 1 || split > 1 || p.geglu || p.out_kind != 0 || (p.N & 7) != 0 || p.N <= 16 ||
             p.bias_per_row || ((p.ld_out | p.ld_res) & 7) != 0 || p.res_f32 ||
             (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0)
+            return SDMI_ERR_BAD_ARG;
+    }
+    if (p.ln_colsum != nullptr) {
+        // LayerNorm folded into the projection: the kernels that gather the row sums are mode 0 / f16 instantiations
+        if (p.dtype != SDMI_DTYPE_F16 || p.mode != 0 || p.A2 != nullptr || batch > 1 || (n_w & 3) != 0 || p.stages == 2 ||
+            p.algo == 2 || p.ln_gamma != nullptr || p.ln_beta != nullptr || !(p.ln_eps >= 0.f) || p.emb != nullptr)
             return SDMI_ERR_BAD_ARG;
     }
     if (p.ln_gamma != nullptr && (p.ln_beta == nullptr || p.algo == 1 || !(p.ln_eps >= 0.f))) return SDMI_ERR_BAD_ARG;
@@ -229,6 +254,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
                                  sdmi_gemm_unit_attrs_m1_f16};
         bool ok = true;
         for (int i = 0; i < 4; ++i) ok = (fns[i]() == SDMI_OK) && ok;
+        ok = (sdmi_gemm_unit_attrs_m0_f16_lnf() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16_lnf() == SDMI_OK) && ok;
         return (sdmi_gemm_wide_attrs_bf16() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16() == SDMI_OK) && ok;
     });
     if (attr_status != SDMI_OK) return attr_status;
@@ -236,7 +262,11 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (BN == 256)        (f16 ? sdmi_gemm_wide_launch_f16 : sdmi_gemm_wide_launch_bf16)(p.mode, grid, s, p);
+    if (p.ln_colsum != nullptr) {
+        if (BN == 256) sdmi_gemm_wide_launch_f16_lnf(0, grid, s, p);
+        else           sdmi_gemm_unit_launch_m0_f16_lnf(wide, tall ? 1 : 0, grid, s, p);
+    }
+    else if (BN == 256)   (f16 ? sdmi_gemm_wide_launch_f16 : sdmi_gemm_wide_launch_bf16)(p.mode, grid, s, p);
     else if (p.mode == 0) (f16 ? sdmi_gemm_unit_launch_m0_f16 : sdmi_gemm_unit_launch_m0_bf16)(wide, variant, grid, s, p);
     else                  (f16 ? sdmi_gemm_unit_launch_m1_f16 : sdmi_gemm_unit_launch_m1_bf16)(wide, variant, grid, s, p);
     SDMI_CHECK_LAUNCH();

@@ -124,6 +124,78 @@ __device__ __forceinline__ void wait_dma(int keep_stages) {
     else                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- LayerNorm folded into the projection (sdmi_gemm_args.ln_colsum; f16 operands) ----
+// The kernel multiplies the RAW rows of A by W' = W * gamma and needs two numbers per row, sum(a) and sum(a^2).  A lane
+// of the MFMA "B" fragment of row block mi holds 8 consecutive k of row (lane & 15): two v_dot2_f32_f16 per 32-bit word
+// beside the MFMAs, and one butterfly over the four lane groups at the end - the row statistics then sit in exactly the
+// lanes whose accumulator quads belong to that row.
+template <int MI>
+__device__ __forceinline__ void lnf_accumulate(const uint4 (&af)[MI], float (&s1)[MI], float (&s2)[MI]) {
+    const f16x2v one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const unsigned w[4] = {af[mi].x, af[mi].y, af[mi].z, af[mi].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x2v h = __builtin_bit_cast(f16x2v, w[j]);
+            s1[mi] = __builtin_amdgcn_fdot2(h, one, s1[mi], false);
+            s2[mi] = __builtin_amdgcn_fdot2(h, h, s2[mi], false);
+        }
+    }
+}
+
+// One sum per lane: sum(a) when `squares` is false, sum(a^2) when true (the 256 x 256 x 32 tile has no registers for both:
+// its two wave columns read the same A fragments and take one sum each).
+template <int MI>
+__device__ __forceinline__ void lnf_accumulate_one(const uint4 (&af)[MI], float (&s)[MI], bool squares) {
+    const f16x2v one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const unsigned w[4] = {af[mi].x, af[mi].y, af[mi].z, af[mi].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x2v h = __builtin_bit_cast(f16x2v, w[j]);
+            s[mi] = __builtin_amdgcn_fdot2(h, squares ? h : one, s[mi], false);
+        }
+    }
+}
+
+// sums of the four lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four k-chunks of one row)
+template <int MI>
+__device__ __forceinline__ void lnf_row_totals(float (&s1)[MI], float (&s2)[MI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        s1[mi] += __shfl_xor(s1[mi], 16);
+        s2[mi] += __shfl_xor(s2[mi], 16);
+        s1[mi] += __shfl_xor(s1[mi], 32);
+        s2[mi] += __shfl_xor(s2[mi], 32);
+    }
+}
+
+__device__ __forceinline__ void lnf_mean_rstd(float s1, float s2, float inv_k, float eps, float& mean, float& rstd) {
+    mean = s1 * inv_k;
+    const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+    rstd = rsqrtf(var + eps);
+}
+
+// acc <- rstd[m] * (acc - mean[m] * colsum[n]) for the wave's TN x MI accumulator quads; wcol0 = the wave's first weight
+// row + 4 * (lane >> 4)
+template <int TN, int MI>
+__device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], const float (&s1)[MI],
+                                          const float (&s2)[MI], int64_t wcol0, int64_t /*n_w*/) {
+    const float inv_k = 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K);
+    float mean[MI], rstd[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) lnf_mean_rstd(s1[mi], s2[mi], inv_k, p.ln_eps, mean[mi], rstd[mi]);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int64_t wcol = wcol0 + ni * 16;
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol);      // (padded to the column tile: sdmi.h)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (acc[ni][mi] - mean[mi] * cs) * rstd[mi];
+    }
+}
+
 // Fast 16-bit epilogue of one wave (row-major output, N % 8 == 0, column bias).  Two 16-column MFMA blocks that are
 // neighbours in N are exchanged between the lane rows with v_permlane16_swap, so a lane owns 8 consecutive output
 // columns of ONE block: stores (and residual loads) become 16 bytes per lane and 64 contiguous bytes per output row
@@ -133,9 +205,12 @@ __device__ __forceinline__ void wait_dma(int keep_stages) {
 #ifndef SDMI_RES_HOIST
 #define SDMI_RES_HOIST 1      // A/B (tools/ab_build.sh): 0 = residual requested row block by row block everywhere
 #endif
-template <int DT, int TN, int MI, int P0, bool HOIST = (SDMI_RES_HOIST != 0)>
+// LNF: the LayerNorm-folded form applied here instead of in place (ln_mean / ln_rstd: the lane's MI rows, LNS floats
+// apart - in LDS for the 256 x 256 x 32 tile, which has no registers for a separate pass over its accumulators).
+template <int DT, int TN, int MI, int P0, bool HOIST = (SDMI_RES_HOIST != 0), bool LNF = false, int LNS = 1>
 __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], int64_t mrow, int64_t ncol_w,
-                                                int fq, int64_t zoff_out, int64_t zoff_res) {
+                                                int fq, int64_t zoff_out, int64_t zoff_res, const float* ln_mean = nullptr,
+                                                const float* ln_rstd = nullptr) {
     const int odd = fq & 1;
     const int64_t ncol0 = ncol_w + 4 * fq;                  // own quad inside block 0
     const int64_t ncol8 = ncol_w + odd * 16 + 4 * (fq & 2); // own 8 columns inside pair 0 (after the swap)
@@ -147,6 +222,11 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
         nval[ni] = n < p.N;
         bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    f32x4 csq[LNF ? TN : 1];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) csq[ni] = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol0 + ni * 16);
     }
     const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
     unsigned short* const outp = reinterpret_cast<unsigned short*>(p.out) + zoff_out;
@@ -198,7 +278,7 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
                 rq[ni + 1] = make_uint2(sx[1], sy[1]);
             }
         }
-        if (p.emb != nullptr) {
+        if (!LNF && p.emb != nullptr) {
             const float* e = p.emb + (mval ? m / p.rows_per_batch : 0) * p.ld_emb;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
@@ -209,14 +289,16 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
         uint2 ov[TN];
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-            f32x4 v = acc[ni][mi] * p.alpha + bq[ni];
+            f32x4 v;
+            if constexpr (LNF) v = (acc[ni][mi] - ln_mean[mi * LNS] * csq[ni]) * (ln_rstd[mi * LNS] * p.alpha) + bq[ni];
+            else               v = acc[ni][mi] * p.alpha + bq[ni];
             if (p.act == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
             } else if (p.act == 2) {
                 v = gelu_erf_f4(v);
             }
-            if (p.emb != nullptr) v += eq[ni];
+            if (!LNF && p.emb != nullptr) v += eq[ni];
             if (p.res != nullptr) {
                 float rf[4];
                 elem_unpack4_sel<DT>(rq[ni], rf, p.res_f16);
@@ -252,10 +334,18 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
 // GEGLU epilogue of one wave over FOUR 16-column weight blocks, 16-bit output (blocks (0,1) and (2,3) are (value, gate)
 // pairs; used by the panel kernel - TN == 4 - and, twice per wave, by the 256 x 256 x 32 tile): the two
 // gated 16-column blocks are paired through v_permlane16_swap - 16-byte stores, 64 contiguous bytes per row.
-template <int DT, int MI>
+template <int DT, int MI, bool LNF = false, int LNS = 1>
 __device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 (&acc)[4][MI], int64_t mrow, int64_t wcol_w,
-                                                 int fq) {
+                                                 int fq, const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
     f32x4 bv[2], bg[2];
+    f32x4 cv[LNF ? 2 : 1], cg[LNF ? 2 : 1];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            cv[pi] = *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol_w + pi * 32 + 4 * fq);
+            cg[pi] = *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol_w + pi * 32 + 4 * fq + 16);
+        }
+    }
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
         const int64_t wcol = wcol_w + pi * 32 + 4 * fq;
@@ -272,7 +362,15 @@ __device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 
         uint2 ov[2];
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
-            f32x4 v = acc[2 * pi][mi] * p.alpha + bv[pi], g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
+            f32x4 v, g;
+            if constexpr (LNF) {
+                const float sc = ln_rstd[mi * LNS] * p.alpha, mu = ln_mean[mi * LNS];
+                v = (acc[2 * pi][mi] - mu * cv[pi]) * sc + bv[pi];
+                g = (acc[2 * pi + 1][mi] - mu * cg[pi]) * sc + bg[pi];
+            } else {
+                v = acc[2 * pi][mi] * p.alpha + bv[pi];
+                g = acc[2 * pi + 1][mi] * p.alpha + bg[pi];
+            }
             v *= gelu_erf_f4(g);
             ov[pi].x = elem_pack2<DT>(v[0], v[1]);
             ov[pi].y = elem_pack2<DT>(v[2], v[3]);
@@ -290,7 +388,8 @@ __device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 
 // 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
 // (the 2-stage variant: two workgroups per CU).  The second __launch_bounds__ argument is waves per SIMD in HIP, not
 // blocks per CU: 4 caps the 2-stage variant at 128 VGPRs so that two of its workgroups really fit.
-template <int MODE, int DT, int TN, int MI, int NST>
+// LNF: the LayerNorm-folded form (ln_colsum; mode 0, f16) - its own instantiations, so no other launch carries the sums.
+template <int MODE, int DT, int TN, int MI, int NST, bool LNF = false>
 __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
     constexpr int BM = 64 * MI;                 // 4 waves across M, MI 16-row blocks each
     constexpr int BN = TN * 32;                 // 2 waves across N, TN 16-column blocks each
@@ -502,6 +601,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     // share of tile t+3 into the stage tile t just vacated, reads the second half of tile t+1 and runs its
     // first-half MFMAs.  Ring: tile t+1 being read, t+2 landed or landing, t+3 in flight.
     uint4 af0[MI], wf0[TN], af1[MI], wf1[TN];
+    float ln_s1[MI], ln_s2[MI];      // LNF: this lane's share of sum(a), sum(a^2) of its MI rows
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ln_s1[i] = ln_s2[i] = 0.f;
 #define SDMI_READ_FRAGS(AF, WF, STAGE, KS)                                                                 \
     do {                                                                                                   \
         const uint4* St_ = lds + (STAGE) * STAGE_CHUNKS;                                                   \
@@ -517,6 +619,21 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 acc[ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[ni_][mi_]);                               \
         if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                   \
     } while (0)
+    // LNF: the row sums of the half k-tile whose MFMAs were just issued.  SDMI_LNF_SPLIT: each wave column takes one of the
+    // two halves of every k-tile (both read the same A fragments), half the VALU work per wave
+#ifndef SDMI_LNF_SPLIT
+#define SDMI_LNF_SPLIT 0
+#endif
+#ifndef SDMI_LNF_VALU_GROUP
+#define SDMI_LNF_VALU_GROUP 0
+#endif
+    const int wn_u = __builtin_amdgcn_readfirstlane(wid) & 1;
+#define SDMI_LNF_ACC(AF, KS)                                                                               \
+    do {                                                                                                   \
+        if constexpr (LNF) {                                                                               \
+            if (!SDMI_LNF_SPLIT || wn_u == (KS)) lnf_accumulate<MI>(AF, ln_s1, ln_s2);                     \
+        }                                                                                                  \
+    } while (0)
 
     // scheduling hint for the region just written: one ds_read, then two MFMAs, MI+TN times (spreads the LDS reads
     // of the next half under the MFMAs of this one instead of bunching them)
@@ -526,6 +643,8 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         _Pragma("unroll") for (int g_ = 0; g_ < MI + TN; ++g_) {                                           \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
+            if constexpr (LNF && SDMI_LNF_VALU_GROUP > 0)                                                  \
+                __builtin_amdgcn_sched_group_barrier(0x002, SDMI_LNF_VALU_GROUP, 0);                       \
         }                                                                                                  \
     } while (0)
 #else
@@ -546,29 +665,69 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         SDMI_READ_FRAGS(af0, wf0, 0, 0);
         SDMI_READ_FRAGS(af1, wf1, 0, 1);
         SDMI_MFMA_HALF(af0, wf0);
+        SDMI_LNF_ACC(af0, 0);
         int rd = 1, wr = 0;                          // ring stage of tile kt+1 / of tile kt (free after the barrier)
         for (int kt = 0; kt + 1 < nk; ++kt) {
             SDMI_WAIT_DMA(kt_issue - kt - 2);        // tile kt+1 landed; younger tiles may still fly
             __syncthreads();                         // every wave has finished READING tile kt as well
             SDMI_READ_FRAGS(af0, wf0, rd, 0);
             SDMI_MFMA_HALF(af1, wf1);                // second half of tile kt
+            if (SDMI_LNF_VALU_GROUP > 0) SDMI_LNF_ACC(af1, 1);
             SDMI_INTERLEAVE();
+            if (SDMI_LNF_VALU_GROUP == 0) SDMI_LNF_ACC(af1, 1);
             if (kt_issue < nk) {
                 SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
                 ++kt_issue;
             }
             SDMI_READ_FRAGS(af1, wf1, rd, 1);
             SDMI_MFMA_HALF(af0, wf0);                // first half of tile kt+1
+            if (SDMI_LNF_VALU_GROUP > 0) SDMI_LNF_ACC(af0, 0);
             SDMI_INTERLEAVE();
+            if (SDMI_LNF_VALU_GROUP == 0) SDMI_LNF_ACC(af0, 0);
             wr = rd;
             rd = rd == NST - 1 ? 0 : rd + 1;
         }
         SDMI_MFMA_HALF(af1, wf1);                    // second half of the last tile
+        SDMI_LNF_ACC(af1, 1);
     }
 
     // ---- epilogue ----
     // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*16*MI + mi*16 + (lane&15),
     // weight row (column of out) wcol = n0 + wn*16*TN + ni*16 + 4*(lane>>4) + j.
+    if constexpr (LNF) {
+        lnf_row_totals<MI>(ln_s1, ln_s2);
+        if (SDMI_LNF_SPLIT) {
+            // each wave column holds the sums of its halves of the k-tiles: add the other column's through LDS (the ring is
+            // idle once every wave is past its last fragment read)
+            f32x2* const xs = reinterpret_cast<f32x2*>(smem);
+            __syncthreads();
+            if (fq == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) xs[wn * BM + wm * (MI * 16) + mi * 16 + frow] = (f32x2){ln_s1[mi], ln_s2[mi]};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const f32x2 o = xs[(wn ^ 1) * BM + wm * (MI * 16) + mi * 16 + frow];
+                ln_s1[mi] += o[0];
+                ln_s2[mi] += o[1];
+            }
+        }
+        if (p.split_k > 1) {
+            // this slice's row sums, behind the slabs: [split][M][2]; one column tile and one wave column write them
+            if (tc.tn == 0 && wn == 0 && fq == 0) {
+                float* st = reinterpret_cast<float*>(p.workspace) + (int64_t)p.split_k * p.M * ((int64_t)tiles_n * BN) +
+                            (int64_t)z * p.M * 2;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
+                    if (m < p.M) *reinterpret_cast<f32x2*>(st + 2 * m) = (f32x2){ln_s1[mi], ln_s2[mi]};
+                }
+            }
+        } else {
+            lnf_apply<TN, MI>(p, acc, ln_s1, ln_s2, n0 + wn * (TN * 16) + 4 * fq, n_w);
+        }
+    }
     if (p.split_k > 1) {
         // raw partial sums to the workspace slab of this slice: [split][M][tiles_n*BN] fp32
         float* ws = reinterpret_cast<float*>(p.workspace) + (int64_t)z * p.M * ((int64_t)tiles_n * BN);
@@ -769,4 +928,26 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     void sdmi_gemm_unit_launch_##NAME(int wide, int variant, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {   \
         hipLaunchKernelGGL(unit_kernels[wide][variant], grid, dim3(512),                                            \
                            lds_bytes(wide ? 5 : 4, variant == 1 ? 4 : 2, variant == 2 ? 2 : 3), s, p);              \
+    }
+
+// The LayerNorm-folded instantiations (mode 0, f16; 128- and 256-row tiles, three stages).
+#define SDMI_GEMM_UNIT_LNF(NAME)                                                                                    \
+    namespace {                                                                                                     \
+    typedef void (*lnf_kern_t)(const sdmi_gemm_args);                                                               \
+    const lnf_kern_t lnf_kernels[2][2] = {                                                                          \
+        {sdmi_gemm_kernel<0, 1, 4, 2, 3, true>, sdmi_gemm_kernel<0, 1, 4, 4, 3, true>},                             \
+        {sdmi_gemm_kernel<0, 1, 5, 2, 3, true>, sdmi_gemm_kernel<0, 1, 5, 4, 3, true>}};                            \
+    }                                                                                                               \
+    int sdmi_gemm_unit_attrs_##NAME() {                                                                             \
+        for (int c = 0; c < 2; ++c)                                                                                 \
+            for (int d = 0; d < 2; ++d)                                                                             \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(lnf_kernels[c][d]),                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,                                 \
+                                        lds_bytes(c ? 5 : 4, d == 1 ? 4 : 2, 3)) != hipSuccess)                     \
+                    return SDMI_ERR_LAUNCH;                                                                         \
+        return SDMI_OK;                                                                                             \
+    }                                                                                                               \
+    void sdmi_gemm_unit_launch_##NAME(int wide, int variant, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {   \
+        hipLaunchKernelGGL(lnf_kernels[wide][variant], grid, dim3(512),                                             \
+                           lds_bytes(wide ? 5 : 4, variant == 1 ? 4 : 2, 3), s, p);                                 \
     }

@@ -44,10 +44,11 @@ class GemmArgs(C.Structure):
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
         ("out_f16", C.c_int32), ("res_f16", C.c_int32), ("a_f16", C.c_int32),
         ("dup_rows", C.c_int32),
+        ("ln_colsum", C.c_void_p),
     ]
 
 
-ABI_VERSION = 11    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 12    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

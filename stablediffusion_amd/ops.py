@@ -6,6 +6,7 @@ policy), channels-last.  An image batch is a contiguous [B, H, W, C] tensor,
 which *is* the token matrix [B*H*W, C] the transformer blocks use (no permutes anywhere).
 """
 import ctypes as C
+import os
 import functools
 import math
 
@@ -94,7 +95,8 @@ def _round_up(x, m):
 class PackedWeight:
     """bf16 [Npad, Kpad] weight (K contiguous) + fp32 bias in the layout sdmi_gemm expects."""
 
-    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN, split_cp=0, out_dtype=None):
+    def __init__(self, w, bias, n_out, k, geglu=False, cin=None, tile_n=_BN, split_cp=0, out_dtype=None, ln_colsum=None,
+                 ln_eps=None):
         # 16-bit type of the layer's OUTPUT when it differs from the operand type: the bf16 operand policy keeps its
         # residual stream in f16 (stream_dtype()), so a layer whose output IS the stream (conv_in, the ResBlock convs,
         # to_out, the feed-forward's second linear, proj_out ...) has bf16 weights and an f16 output
@@ -108,6 +110,11 @@ class PackedWeight:
         self.k = k              # padded K
         self.geglu = geglu
         self.cin = cin          # conv3x3: (padded) input channels
+        # LayerNorm folded into the projection (sdmi_gemm_args.ln_colsum): `w` holds W * gamma, `bias` holds
+        # bias + W @ beta, ln_colsum [Npad] fp32 the row sums of the packed (rounded) weights; linear() then takes the RAW
+        # input and the kernel normalises through two numbers per row
+        self.ln_colsum = ln_colsum
+        self.ln_eps = ln_eps
 
 
 _SPLIT_PAD = 32       # fp32 mode: plane width padding (6 * 32 = 3 GEMM k-tiles, and a conv tap never straddles a k-tile)
@@ -163,29 +170,61 @@ def _pack_rows(ws, out, code, tile_n):
         off += n
 
 
-def pack_linear(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None):
+# False (env SDMI_FOLD_LN=0): pack_*(ln=...) keeps the plain weights and linear(ln=...) normalises as rounds 1-2 did (tests, A/B)
+FOLD_LN = os.environ.get("SDMI_FOLD_LN", "1") != "0"
+
+
+def _ln_folds(dtype, ln):
+    """Whether a projection behind a LayerNorm is packed in the folded form: f16 operands only - the kernels that gather
+    the row sums are f16 instantiations, and under bf16 operands the raw input is the f16 stream, not an MFMA operand."""
+    return bool(ln is not None and FOLD_LN and FUSE_LN and dtype == F16)
+
+
+def _fold_ln(w, b, ln):
+    """(W * gamma, bias + W @ beta) of a projection behind LayerNorm(gamma, beta): LayerNorm(x) @ W^T + bias =
+    rstd * (x @ (W * gamma)^T - mean * rowsum(W * gamma)) + (bias + W @ beta)."""
+    gamma, beta = _src(ln[0]).to(w.device), _src(ln[1]).to(w.device)
+    extra = (w.double() @ beta.double()).float()
+    return (w * gamma[None, :]).contiguous(), (extra if b is None else (b + extra)).contiguous()
+
+
+def _ln_colsum(packed):
+    """Row sums of the PACKED weights (the rounded values the MFMA multiplies, in packed row order, 0 for padding rows)."""
+    return packed.double().sum(dim=1).float().contiguous()
+
+
+def pack_linear(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None, ln=None):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
-    return pack_linear_cat([weight], None if bias is None else [bias], dtype=dtype, tile_n=tile_n, out_dtype=out_dtype)
+    return pack_linear_cat([weight], None if bias is None else [bias], dtype=dtype, tile_n=tile_n, out_dtype=out_dtype,
+                           ln=ln)
 
 
-def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=None):
-    """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections)."""
+def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=None, ln=None):
+    """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections).
+    ln = (gamma, beta[, eps]) of the nn.LayerNorm the projection's input goes through: with f16 operands the norm is folded
+    into the packed weights (PackedWeight.ln_colsum) and linear() takes the un-normalised input."""
     ws = [_src(x.reshape(x.shape[0], -1)) for x in weights]
     n = sum(w.shape[0] for w in ws)
     k = ws[0].shape[1]
     b = torch.cat([_src(x) for x in biases]).contiguous() if biases is not None else None
+    fold = _ln_folds(dtype, ln)
+    if fold:
+        wcat, b = _fold_ln(torch.cat(ws), b, ln)
+        ws = [wcat]
     code, tdt = _pack_dt(dtype)
     tn = tile_n or hip.lib().sdmi_pack_tile_n(n, 0)
     kp = hip.lib().sdmi_pack_linear_k(k, code)
     out = _pack_alloc(n, kp, tn, tdt, ws[0].device)
     _pack_rows(ws, out, code, tn)
     return PackedWeight(out, b, n, kp, tile_n=tn, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
-                        out_dtype=out_dtype if dtype != torch.float32 else None)
+                        out_dtype=out_dtype if dtype != torch.float32 else None,
+                        ln_colsum=_ln_colsum(out) if fold else None, ln_eps=(ln[2] if len(ln) > 2 else 1e-5) if fold else None)
 
 
-def pack_geglu(weight, bias, dtype=BF16):
+def pack_geglu(weight, bias, dtype=BF16, ln=None):
     """GEGLU projection [2*inner, K]: rows [0,inner) = value, [inner,2*inner) = gate (attention.py:89).
-    Packed row r holds value (half 0) or gate (half 1) column blk*16+i with blk=r//32, half=(r%32)//16, i=r%16."""
+    Packed row r holds value (half 0) or gate (half 1) column blk*16+i with blk=r//32, half=(r%32)//16, i=r%16.
+    ln: as pack_linear_cat."""
     w = _src(weight)
     inner, k = w.shape[0] // 2, w.shape[1]
     assert inner % 16 == 0
@@ -193,13 +232,17 @@ def pack_geglu(weight, bias, dtype=BF16):
     kp = hip.lib().sdmi_pack_linear_k(k, code)
     out = _pack_alloc(2 * inner, kp, _BN, tdt, w.device)
     b = _src(bias) if bias is not None else None
+    fold = _ln_folds(dtype, ln)
+    if fold:
+        w, b = _fold_ln(w, b, ln)
     bo = torch.empty_like(b) if b is not None else None
     if w.is_cuda:
         st = hip.lib().sdmi_pack_geglu(_p(w), _p(b), inner, k, k, _p(out), _p(bo), code, _stream())
     else:
         st = hip.lib().sdmi_pack_geglu_host(_p(w), _p(b), inner, k, k, _p(out), _p(bo), code)
     hip.check(st, "sdmi_pack_geglu")
-    return PackedWeight(out, bo, inner, kp, geglu=True, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0)
+    return PackedWeight(out, bo, inner, kp, geglu=True, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
+                        ln_colsum=_ln_colsum(out) if fold else None, ln_eps=(ln[2] if len(ln) > 2 else 1e-5) if fold else None)
 
 
 def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None):
@@ -426,6 +469,11 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     duplication of the UNet written by the producing launch)."""
     if dup_rows and (pw.split_cp or out_nchw_f32 is not None or (out_dtype is not None and out_dtype not in HALF_TYPES)):
         raise hip.SdmiError("linear: dup_rows needs a 16-bit row-major output")
+    if pw.ln_colsum is not None:
+        # the LayerNorm lives in the packed weights (pack_*(ln=...)): the kernel takes the raw input
+        if ln is None or x2 is not None or emb is not None:
+            raise hip.SdmiError("linear: this weight was packed behind a LayerNorm (ln=...): pass ln, no x2, no emb")
+        ln = None
     if ln is not None and (pw.split_cp or x2 is not None or not FUSE_LN):
         x, ln = layernorm(x, *ln, out_dtype=None if pw.split_cp else pw.dtype), None
     if pw.split_cp:
@@ -442,6 +490,8 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     a.A = x.data_ptr()
     a.lda = k1
     a.M = m
+    if pw.ln_colsum is not None:
+        a.ln_colsum, a.ln_eps = pw.ln_colsum.data_ptr(), pw.ln_eps
     if x2 is not None:
         _require(x2, pw.dtype, "x2")
         a.A2 = x2.data_ptr()

@@ -147,11 +147,14 @@ def pack_spatial_transformer(st, cd, kv_off=0):
             "ln1": (f32(tb.norm1.weight), f32(tb.norm1.bias)),
             "ln2": (f32(tb.norm2.weight), f32(tb.norm2.bias)),
             "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
-            "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd),
+            # (ln=: with f16 operands the three LayerNorms are folded into the projections they feed - ops.pack_linear_cat)
+            "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd,
+                                        ln=(tb.norm1.weight, tb.norm1.bias, tb.norm1.eps)),
             "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd, out_dtype=sd),
-            "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd),
+            "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd, ln=(tb.norm2.weight, tb.norm2.bias, tb.norm2.eps)),
             "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd, out_dtype=sd),
-            "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd),
+            "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd,
+                                    ln=(tb.norm3.weight, tb.norm3.bias, tb.norm3.eps)),
             "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd, out_dtype=sd),
             "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
         }

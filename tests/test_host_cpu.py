@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == set(hip.SIGNATURES), "ctypes binding and header disagree"
     assert lib.sdmi_abi_version() == hip.ABI_VERSION >= 4
     assert b"workspace" in lib.sdmi_status_str(-3) and b"no-allocation" in lib.sdmi_status_str(-5)
-    assert lib.sdmi_gemm_workspace_bytes(128, 1280, 4) == 4 * 128 * 1280 * 4
+    assert lib.sdmi_gemm_workspace_bytes(128, 1280, 4) == 4 * 128 * (1280 + 2) * 4      # slabs + the row sums of a folded LayerNorm
     assert lib.sdmi_gemm_workspace_bytes(128, 1280, 1) == 0
     assert lib.sdmi_groupnorm_workspace_bytes(2, 4096) > 0
 

@@ -719,6 +719,72 @@ def test_fused_layernorm_falls_back_and_refuses(dev):
     assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # SDMI_ERR_BAD_ARG
 
 
+@pytest.mark.parametrize("kind,m,k,n,res", [
+    ("lin", 300, 320, 960, False),          # 128-row tile, ragged rows
+    ("lin", 16384, 320, 320, True),         # 256-row tile + residual
+    ("lin", 2100, 640, 1920, False),
+    ("lin", 512, 1280, 1280, False),        # split-K: the row sums travel with the slabs
+    ("lin", 4096, 1280, 3840, False),       # the 256 x 256 x 32 tile, plain epilogue
+    ("geglu", 1000, 320, 1280, False),      # tiled GEGLU
+    ("geglu", 16384, 640, 2560, False),     # the 256 x 256 x 32 tile, GEGLU epilogue
+    ("geglu", 256, 1280, 5120, False),      # split-K + GEGLU
+])
+def test_layernorm_folded_into_the_projection(dev, kind, m, k, n, res):
+    """pack_*(ln=...) with f16 operands: W * gamma is packed, the kernel multiplies the RAW input and applies
+    rstd * (acc - mean * rowsum(W')) - sdmi_gemm_args.ln_colsum.  Against torch in fp32 (LayerNorm of attention.py:512-514
+    + the projection), and against the unfolded path (sdmi_layernorm / the panel kernel + the same GEMM): the folded form
+    drops the f16 rounding of the normalised operand, so it must not be further from fp32 than the unfolded one."""
+    ops = _ops()
+    qd = lambda t: t.to(F16).float()
+    # rows with different means and scales, a residual-stream-like input
+    x = (rnd((m, k), dev, 61) * (0.5 + 2.0 * torch.rand(m, 1, device=dev)) + 1.5 * rnd((m, 1), dev, 62)).to(F16)
+    gamma, beta = 1.0 + 0.2 * rnd((k,), dev, 63), 0.3 * rnd((k,), dev, 64)
+    ln = (gamma, beta, 1e-5)
+    r = rnd((m, n), dev, 67).to(F16) if res else None
+    if kind == "geglu":
+        w, b = rnd((2 * n, k), dev, 65, 0.06), rnd((2 * n,), dev, 66)
+        folded, plain = ops.pack_geglu(w, b, dtype=F16, ln=ln), ops.pack_geglu(w, b, dtype=F16)
+    else:
+        w, b = rnd((n, k), dev, 65, 0.06), rnd((n,), dev, 66)
+        folded, plain = ops.pack_linear(w, b, dtype=F16, ln=ln), ops.pack_linear(w, b, dtype=F16)
+    assert folded.ln_colsum is not None and plain.ln_colsum is None
+    out = ops.linear(x, folded, ln=ln, res=r)
+    old = ops.linear(x, plain, ln=ln, res=r)
+    ref = F.linear(F.layer_norm(x.float(), (k,), gamma, beta, 1e-5), w, b)
+    if kind == "geglu":
+        a_, g_ = ref.chunk(2, dim=-1)
+        ref = a_ * F.gelu(g_)
+    if res:
+        ref = ref + r.float()
+    e_new, e_old = rel_err(out, ref), rel_err(old, ref)
+    assert e_new < 1.5e-3, (e_new, e_old)
+    assert e_new < 1.25 * e_old + 1e-4, (e_new, e_old)
+    with pytest.raises(ops.hip.SdmiError):
+        ops.linear(x, folded)                       # a folded weight needs the caller to say it knows (ln=...)
+
+
+def test_layernorm_fold_is_f16_only_and_checked(dev):
+    ops = _ops()
+    gamma, beta = 1.0 + 0.2 * rnd((320,), dev, 63), 0.3 * rnd((320,), dev, 64)
+    w = rnd((320, 320), dev, 65, 0.06)
+    assert ops.pack_linear(w, dtype=BF16, ln=(gamma, beta)).ln_colsum is None       # bf16 operands: the f16 stream is no operand
+    pw = ops.pack_linear(w, dtype=F16, ln=(gamma, beta))
+    x = rnd((256, 320), dev, 61).to(F16)
+    a = ops.hip.GemmArgs()
+    o = torch.empty(256, 320, dtype=F16, device=dev)
+    a.mode, a.A, a.lda, a.M, a.W, a.N, a.K = 0, x.data_ptr(), 320, 256, pw.w.data_ptr(), 320, 320
+    a.out, a.ld_out, a.dtype, a.tile_n, a.alpha, a.batch, a.split_k = o.data_ptr(), 320, 1, pw.tile_n, 1.0, 1, 1
+    a.ln_colsum, a.ln_eps = pw.ln_colsum.data_ptr(), 1e-5
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == 0
+    a.dtype = 0
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # bf16 operands
+    a.dtype, a.stages = 1, 2
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # the two-stage variant has no folded instantiation
+    a.stages, a.ln_gamma, a.ln_beta = 0, gamma.data_ptr(), beta.data_ptr()
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # folded and unfolded at once
+    torch.cuda.synchronize()
+
+
 def test_panel_gemm_refuses_what_it_is_not_built_for(dev):
     ops = _ops()
     x, pw = rnd((4096, 640), dev, 38).to(BF16), ops.pack_linear(rnd((640, 640), dev, 39))
