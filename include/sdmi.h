@@ -45,7 +45,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 12: + sdmi_gemm_args.ln_colsum (LayerNorm folded into the projection); 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 12: + sdmi_gemm_args.ln_colsum / ln_stats / row_stats_out (LayerNorm folded into the projection, row statistics travelling with the residual stream), sdmi_gemm_row_stats_slots, sdmi_row_stats; 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -131,18 +131,29 @@ typedef struct sdmi_gemm_args {
                                            with the 16-bit row-major fast epilogue (out_kind 0, no GEGLU, N % 8 == 0, column
                                            bias, ld_out % 8 == 0, ld_res % 8 == 0, 16-byte aligned out / res), batch 1,
                                            split_k 1 and N > 16 - SDMI_ERR_BAD_ARG otherwise */
-    /* ln_colsum non-NULL: the nn.LayerNorm in front of the projection (attention.py:512-514, 528-541) FOLDED into it - no
+    /* ---- the token stream of the transformer blocks (dtype SDMI_DTYPE_F16, mode 0, no A2, no emb, column bias, batch 1,
+       N_w % 4 == 0, stages != 2, algo != 2, ln_gamma NULL - SDMI_ERR_BAD_ARG otherwise) ----
+       ln_colsum non-NULL: the nn.LayerNorm in front of the projection (attention.py:512-514, 528-541) FOLDED into it - no
        normalised copy of A exists at any point.  With W' = W * gamma[k] (the caller packs W', rounded to f16) and
-           colsum[n] = sum_k W'[n, k]   (of the rounded values, in packed weight-row order: the GEGLU interleave included),
+           colsum[n] = sum_k W'[n, k]   (of the rounded values, one float per PACKED weight row: the GEGLU interleave and the
+                                         zero padding rows included - what summing the packed buffer's rows gives),
            bias'[n]  = bias[n] + sum_k beta[k] * W[n, k]   (passed as `bias`),
        LayerNorm(a) @ W^T + bias = rstd[m] * (a @ W'^T - mean[m] * colsum[n]) + bias'[n]: the kernel multiplies the RAW rows
-       of A, gathers sum(a) and sum(a^2) of every row from the operand fragments it already holds (biased variance, fp32,
-       eps = ln_eps) and applies the two per-row numbers to the accumulators in front of the usual epilogue.  With split_k
-       > 1 the per-slice row sums travel in the workspace behind the slabs (sdmi_gemm_workspace_bytes counts them) and the
-       reduce pass applies them.  dtype SDMI_DTYPE_F16, mode 0, no A2, no emb, batch 1, N_w % 4 == 0, stages != 2, algo != 2,
-       ln_gamma NULL - SDMI_ERR_BAD_ARG otherwise.  `colsum` holds one float per PACKED weight row (N_w rounded up to the
-       tile the weight was packed for, 0 for the padding rows: what summing the packed buffer's rows gives). */
+       of A and applies two numbers per row in front of the usual epilogue (with split_k > 1: in the reduce pass).  They come
+       from ln_stats [M][ln_stats_slots][2] = per row and slot the partial (sum a, sum a^2) over the row's K columns (biased
+       variance, fp32, eps = ln_eps; ln_stats_slots even and <= 32, or 1 | 3; 16-byte aligned) - left there by the launch that PRODUCED A
+       through row_stats_out, or by sdmi_row_stats. */
     const float* ln_colsum;
+    const float* ln_stats;
+    int32_t ln_stats_slots;
+    /* row_stats_out non-NULL: besides storing `out`, the launch leaves the row sums of the values it stores (fp32, before
+       the rounding to f16) in row_stats_out [M (2 M with dup_rows)][row_stats_slots][2]; row_stats_slots must equal
+       sdmi_gemm_row_stats_slots(args) (one slot per (column tile, wave column) of the kernel the plan in args selects; one per
+       1024 columns with split_k > 1).  16-bit row-major output with the conditions of dup_rows (split_k > 1 allowed without dup_rows), no GEGLU.
+       This is how to_out + residual, the feed-forward's second linear and proj_in hand the statistics of the residual
+       stream to the LayerNorm-folded projection that reads it next. */
+    int32_t row_stats_slots;
+    float* row_stats_out;
 } sdmi_gemm_args;
 
 int sdmi_gemm(const sdmi_gemm_args* args, void* stream);
@@ -153,6 +164,12 @@ int sdmi_gemm_panel_applies(const sdmi_gemm_args* args);
    aligned out / res with ld % 8 == 0) or the 16-bit GEGLU epilogue (N % 32 == 0, no res / emb / act, batch 1).  Has no
    say on whether W is padded to 256 rows. */
 int sdmi_gemm_wide_applies(const sdmi_gemm_args* args);
+/* Slots per row a launch with these args (tile_n, split_k, N as they will be passed) writes to row_stats_out. */
+int32_t sdmi_gemm_row_stats_slots(const sdmi_gemm_args* args);
+/* Row statistics of a 16-bit [rows, C] matrix in the layout of sdmi_gemm_args.ln_stats with one slot:
+   stats[r] = (sum_c x[r, c], sum_c x[r, c]^2), fp32.  For a LayerNorm-folded projection whose input was not produced by a
+   launch with row_stats_out (the reference has no counterpart: its nn.LayerNorm computes them on the fly).  C % 8 == 0. */
+int sdmi_row_stats(const void* x, float* stats, int64_t rows, int32_t C, int32_t dtype, void* stream);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);

@@ -40,19 +40,6 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
             v += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol);
             if (p.geglu) g += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol + 16);
         }
-        if (p.ln_colsum != nullptr) {
-            // LayerNorm folded into the projection: the slices' row sums sit behind the slabs ([split][M][2])
-            const float* st = ws + p.split_k * slab;
-            float s1 = 0.f, s2 = 0.f;
-            for (int s = 0; s < p.split_k; ++s) {
-                s1 += st[(s * p.M + m) * 2];
-                s2 += st[(s * p.M + m) * 2 + 1];
-            }
-            float mean, rstd;
-            lnf_mean_rstd(s1, s2, 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K), p.ln_eps, mean, rstd);
-            v = (v - mean * *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol)) * rstd;
-            if (p.geglu) g = (g - mean * *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol + 16)) * rstd;
-        }
         v *= p.alpha;
         int64_t n = wcol;
         if (p.geglu) {
@@ -73,6 +60,82 @@ __global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce(const sdmi_gemm_a
         }
         if (n >= p.N) continue;
         store_quad<DT>(p, m, n, v, 0, 0);
+    }
+}
+
+// The reduce pass of the token-stream launches (ln_colsum and / or row_stats_out): a workgroup owns 256 quads (1024 weight
+// columns) of ONE output row - blockIdx.x = row, blockIdx.y = column chunk - so the row's statistics are one uniform read
+// (folded LayerNorm in) and its sums one block reduction away (row statistics out: slot = chunk).
+constexpr int REDUCE_ROWS_CHUNK = 1024;
+template <int DT>
+__global__ __launch_bounds__(256) void sdmi_gemm_splitk_reduce_rows(const sdmi_gemm_args p, int64_t ldw) {
+    __shared__ float part[8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t m = blockIdx.x;
+    const int64_t n_w = p.geglu ? 2 * p.N : p.N;
+    const int64_t wcol = (int64_t)blockIdx.y * REDUCE_ROWS_CHUNK + 4 * threadIdx.x;      // (host-checked: N_w % 4 == 0)
+    const float* ws = reinterpret_cast<const float*>(p.workspace);
+    const int64_t slab = p.M * ldw;
+    float mean = 0.f, rstd = 1.f;
+    if (p.ln_colsum != nullptr) {      // (uniform) lane l fetches slot l of the row, a butterfly adds them up: one round trip
+        f32x2 t = (f32x2){0.f, 0.f};
+        if (lane < p.ln_stats_slots) t = reinterpret_cast<const f32x2*>(p.ln_stats)[m * p.ln_stats_slots + lane];
+        float s1 = t[0], s2 = t[1];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+        }
+        lnf_mean_rstd(s1, s2, 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K), p.ln_eps, mean, rstd);
+    }
+    float st1 = 0.f, st2 = 0.f;
+    if (wcol < n_w && !(p.geglu && (wcol & 16))) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f}, g = v;
+        for (int s = 0; s < p.split_k; ++s) {
+            v += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol);
+            if (p.geglu) g += *reinterpret_cast<const f32x4*>(ws + s * slab + m * ldw + wcol + 16);
+        }
+        if (p.ln_colsum != nullptr) {
+            v = (v - mean * *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol)) * rstd;
+            if (p.geglu) g = (g - mean * *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol + 16)) * rstd;
+        }
+        v *= p.alpha;
+        int64_t n = wcol;
+        if (p.geglu) {
+            g *= p.alpha;
+            n = (wcol >> 5) * 16 + (wcol & 15);
+            if (p.bias != nullptr) {
+                v += *reinterpret_cast<const f32x4*>(p.bias + wcol);
+                g += *reinterpret_cast<const f32x4*>(p.bias + wcol + 16);
+            }
+            if (p.out_kind != 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_precise(g[j]);
+            } else {
+                v *= gelu_erf_f4(g);
+            }
+        } else if (p.bias != nullptr) {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) v[j] += p.bias[n + j];
+        }
+        if (n < p.N) {
+            v = store_quad<DT>(p, m, n, v, 0, 0);
+            for (int j = 0; j < 4 && n + j < p.N; ++j) {
+                st1 += v[j];
+                st2 += v[j] * v[j];
+            }
+        }
+    }
+    if (p.row_stats_out != nullptr) {      // (uniform)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            st1 += __shfl_xor(st1, off);
+            st2 += __shfl_xor(st2, off);
+        }
+        if (lane == 0) { part[wid] = st1; part[4 + wid] = st2; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            reinterpret_cast<f32x2*>(p.row_stats_out)[m * p.row_stats_slots + blockIdx.y] =
+                (f32x2){(part[0] + part[1]) + (part[2] + part[3]), (part[4] + part[5]) + (part[6] + part[7])};
     }
 }
 
@@ -112,8 +175,7 @@ extern "C" int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t spl
     // enough for any column tile (128, 160 or 256)
     int64_t ldw = slab_ld(N_w, 128) > slab_ld(N_w, 160) ? slab_ld(N_w, 128) : slab_ld(N_w, 160);
     if (slab_ld(N_w, 256) > ldw) ldw = slab_ld(N_w, 256);
-    // (+ the per-slice row sums of a LayerNorm-folded launch, ln_colsum: [split][M][2])
-    return (int64_t)split_k * M * (ldw + 2) * (int64_t)sizeof(float);
+    return (int64_t)split_k * M * ldw * (int64_t)sizeof(float);
 }
 
 // The 256 x 256 x 32 tile (sdmi_gemm_wide.h) runs whole k-tiles from plain row / tap pointers and has two epilogues: the
@@ -143,6 +205,17 @@ static bool wide_applies(const sdmi_gemm_args& p) {
 }
 
 extern "C" int sdmi_gemm_wide_applies(const sdmi_gemm_args* a) { return a != nullptr && wide_applies(*a) ? 1 : 0; }
+
+// Slots per row a launch with row_stats_out writes: one per (column tile, wave column) of the tiled kernel, one per
+// 64-column run of the 256 x 256 x 32 tile, one per 1024 columns of the split-K reduce pass.
+static int row_stats_slots(const sdmi_gemm_args& p) {
+    if (p.split_k > 1) return (int)((p.N + REDUCE_ROWS_CHUNK - 1) / REDUCE_ROWS_CHUNK);      // (the row-wise reduce pass)
+    const int BN = p.tile_n == 0 ? 128 : p.tile_n;
+    const int64_t tiles_n = (p.N + BN - 1) / BN;
+    return (int)(tiles_n * (BN == 256 ? 4 : 2));
+}
+
+extern "C" int32_t sdmi_gemm_row_stats_slots(const sdmi_gemm_args* a) { return a == nullptr ? 0 : row_stats_slots(*a); }
 
 extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->out == nullptr) return SDMI_ERR_BAD_ARG;
@@ -197,8 +270,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
     if (split > 1) {
         if (split > p.K / BK) return SDMI_ERR_BAD_ARG;
-        const int64_t row_floats = slab_ld(n_w, BN) + (p.ln_colsum != nullptr ? 2 : 0);
-        if (p.workspace == nullptr || p.workspace_bytes < (int64_t)split * p.M * row_floats * (int64_t)sizeof(float))
+        if (p.workspace == nullptr || p.workspace_bytes < (int64_t)split * p.M * slab_ld(n_w, BN) * (int64_t)sizeof(float))
             return SDMI_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -219,11 +291,22 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
             (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0)
             return SDMI_ERR_BAD_ARG;
     }
-    if (p.ln_colsum != nullptr) {
-        // LayerNorm folded into the projection: the kernels that gather the row sums are mode 0 / f16 instantiations
+    if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) {
+        // the token-stream launches (folded LayerNorm in, row statistics out): mode 0 / f16 instantiations of their own
         if (p.dtype != SDMI_DTYPE_F16 || p.mode != 0 || p.A2 != nullptr || batch > 1 || (n_w & 3) != 0 || p.stages == 2 ||
-            p.algo == 2 || p.ln_gamma != nullptr || p.ln_beta != nullptr || !(p.ln_eps >= 0.f) || p.emb != nullptr)
+            p.algo == 2 || p.ln_gamma != nullptr || p.ln_beta != nullptr || p.emb != nullptr || p.bias_per_row)
             return SDMI_ERR_BAD_ARG;
+        if (p.ln_colsum != nullptr && (p.ln_stats == nullptr || p.ln_stats_slots < 1 || p.ln_stats_slots > 32 ||
+                                       ((p.ln_stats_slots & 1) && p.ln_stats_slots > 4) || (((uintptr_t)p.ln_stats) & 15) != 0 || !(p.ln_eps >= 0.f)))
+            return SDMI_ERR_BAD_ARG;
+        if (p.ln_colsum == nullptr && p.ln_stats != nullptr) return SDMI_ERR_BAD_ARG;
+        if (p.geglu && p.ln_colsum == nullptr) return SDMI_ERR_BAD_ARG;       // (a GEGLU output is never the stream)
+        if (p.row_stats_out != nullptr) {
+            // written by the fast 16-bit epilogue (or the row-wise reduce pass): its conditions, as for dup_rows
+            if (p.geglu || p.out_kind != 0 || (p.N & 7) != 0 || p.N <= 16 || ((p.ld_out | p.ld_res) & 7) != 0 || p.res_f32 ||
+                (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0 || p.row_stats_slots != row_stats_slots(p))
+                return SDMI_ERR_BAD_ARG;
+        }
     }
     if (p.ln_gamma != nullptr && (p.ln_beta == nullptr || p.algo == 1 || !(p.ln_eps >= 0.f))) return SDMI_ERR_BAD_ARG;
     if (p.ln_gamma == nullptr && p.ln_beta != nullptr) return SDMI_ERR_BAD_ARG;
@@ -262,7 +345,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (p.ln_colsum != nullptr) {
+    if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) {
         if (BN == 256) sdmi_gemm_wide_launch_f16_lnf(0, grid, s, p);
         else           sdmi_gemm_unit_launch_m0_f16_lnf(wide, tall ? 1 : 0, grid, s, p);
     }
@@ -270,7 +353,12 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     else if (p.mode == 0) (f16 ? sdmi_gemm_unit_launch_m0_f16 : sdmi_gemm_unit_launch_m0_bf16)(wide, variant, grid, s, p);
     else                  (f16 ? sdmi_gemm_unit_launch_m1_f16 : sdmi_gemm_unit_launch_m1_bf16)(wide, variant, grid, s, p);
     SDMI_CHECK_LAUNCH();
-    if (split > 1) {
+    if (split > 1 && (p.ln_colsum != nullptr || p.row_stats_out != nullptr)) {
+        if (p.M > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;      // (one workgroup row per output row)
+        const dim3 rgrid((unsigned)p.M, (unsigned)((n_w + REDUCE_ROWS_CHUNK - 1) / REDUCE_ROWS_CHUNK));
+        hipLaunchKernelGGL(sdmi_gemm_splitk_reduce_rows<1>, rgrid, dim3(256), 0, s, p, tiles_n * BN);
+        SDMI_CHECK_LAUNCH();
+    } else if (split > 1) {
         const int64_t quads = p.M * ((n_w + 3) / 4);
         const int64_t blocks = (quads + 255) / 256;
         const dim3 rgrid((unsigned)(blocks < 4096 ? blocks : 4096));

@@ -46,10 +46,10 @@ __device__ __forceinline__ TileCoord tile_of_block(int bid, int tiles_m, int til
 }
 
 // Epilogue for 4 consecutive output columns of one row.  `v` is the raw accumulator quad (already
-// scaled and biased by the caller for the column-bias / GEGLU cases).
+// scaled and biased by the caller for the column-bias / GEGLU cases).  Returns the fp32 values it stored (rounded).
 template <int DT>
-__device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, int64_t n, f32x4 v,
-                                           int64_t zoff_out, int64_t zoff_res) {
+__device__ __forceinline__ f32x4 store_quad(const sdmi_gemm_args& p, int64_t m, int64_t n, f32x4 v,
+                                            int64_t zoff_out, int64_t zoff_res) {
     if (p.bias != nullptr && p.bias_per_row) {      // epilogue order of include/sdmi.h: bias, then act
         const float b = p.bias[m];
 #pragma unroll
@@ -113,6 +113,7 @@ __device__ __forceinline__ void store_quad(const sdmi_gemm_args& p, int64_t m, i
         float* o = reinterpret_cast<float*>(p.out) + zoff_out + (b * p.N + n) * p.rows_per_batch + pix;
         for (int j = 0; j < 4 && n + j < p.N; ++j) o[j * p.rows_per_batch] = v[j];
     }
+    return v;
 }
 
 // Wait until at most `keep_stages` (0, 1, 2) of this wave's youngest ring stages (PER LDS-DMA instructions each)
@@ -124,52 +125,24 @@ __device__ __forceinline__ void wait_dma(int keep_stages) {
     else                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---- LayerNorm folded into the projection (sdmi_gemm_args.ln_colsum; f16 operands) ----
-// The kernel multiplies the RAW rows of A by W' = W * gamma and needs two numbers per row, sum(a) and sum(a^2).  A lane
-// of the MFMA "B" fragment of row block mi holds 8 consecutive k of row (lane & 15): two v_dot2_f32_f16 per 32-bit word
-// beside the MFMAs, and one butterfly over the four lane groups at the end - the row statistics then sit in exactly the
-// lanes whose accumulator quads belong to that row.
-template <int MI>
-__device__ __forceinline__ void lnf_accumulate(const uint4 (&af)[MI], float (&s1)[MI], float (&s2)[MI]) {
-    const f16x2v one = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const unsigned w[4] = {af[mi].x, af[mi].y, af[mi].z, af[mi].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16x2v h = __builtin_bit_cast(f16x2v, w[j]);
-            s1[mi] = __builtin_amdgcn_fdot2(h, one, s1[mi], false);
-            s2[mi] = __builtin_amdgcn_fdot2(h, h, s2[mi], false);
-        }
-    }
-}
-
-// One sum per lane: sum(a) when `squares` is false, sum(a^2) when true (the 256 x 256 x 32 tile has no registers for both:
-// its two wave columns read the same A fragments and take one sum each).
-template <int MI>
-__device__ __forceinline__ void lnf_accumulate_one(const uint4 (&af)[MI], float (&s)[MI], bool squares) {
-    const f16x2v one = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const unsigned w[4] = {af[mi].x, af[mi].y, af[mi].z, af[mi].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16x2v h = __builtin_bit_cast(f16x2v, w[j]);
-            s[mi] = __builtin_amdgcn_fdot2(h, squares ? h : one, s[mi], false);
-        }
-    }
-}
-
-// sums of the four lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the four k-chunks of one row)
-template <int MI>
-__device__ __forceinline__ void lnf_row_totals(float (&s1)[MI], float (&s2)[MI]) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        s1[mi] += __shfl_xor(s1[mi], 16);
-        s2[mi] += __shfl_xor(s2[mi], 16);
-        s1[mi] += __shfl_xor(s1[mi], 32);
-        s2[mi] += __shfl_xor(s2[mi], 32);
-    }
+// ---- LayerNorm folded into the projection (sdmi_gemm_args.ln_colsum / ln_stats; f16 operands) ----
+// The kernel multiplies the RAW rows of A by W' = W * gamma; LayerNorm(a) @ W^T = rstd[m] * (a @ W'^T - mean[m] * colsum[n]).
+// The two numbers per row come from the launch that PRODUCED A (the residual stream of the transformer blocks:
+// to_out + residual, ff2 + residual, proj_in), whose epilogue leaves per row and per (column tile, wave column) "slot" the
+// partial sum(a), sum(a^2) of the fp32 values it is about to round and store (sdmi_gemm_args.row_stats_out).  A first
+// form gathered the sums inside the consuming kernel (v_dot2_f32_f16 on the activation fragments beside the MFMAs): 5-26 %
+// of the GEMM, more than the LayerNorm launch it replaced on the GEGLU projections
+// (profiles/r03_lnfold_inkernel_experiment.txt).
+// x summed over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (every lane gets the total): two swaps on the VALU
+// (v_permlane16_swap: rows 1 / 3 of the first operand <-> rows 0 / 2 of the second; v_permlane32_swap: upper half of the
+// first <-> lower half of the second) instead of two trips through the LDS crossbar (ds_bpermute).
+__device__ __forceinline__ float sum_lane_groups(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned v = __builtin_bit_cast(unsigned, y);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
 __device__ __forceinline__ void lnf_mean_rstd(float s1, float s2, float inv_k, float eps, float& mean, float& rstd) {
@@ -178,15 +151,63 @@ __device__ __forceinline__ void lnf_mean_rstd(float s1, float s2, float inv_k, f
     rstd = rsqrtf(var + eps);
 }
 
+// mean / rstd of the MI rows a lane's accumulator quads belong to (rows mrow0 + 16 * mi) from the producer's slots,
+// ln_stats[m][slot] = (sum, sum of squares).  The four lanes that share a row (lane >> 4 = 0..3) split the slots between
+// them - pairs of slots as one 16-byte load where the slot count is even -, every load of a batch (MI rows x 2 steps = 16
+// slots per row) is in flight at once, and a butterfly adds up: one round trip for up to 16 slots, two for up to 32, issued
+// in the epilogue next to the bias / colsum loads (a serial walk over 16 slots per row measured +78 us on a 120 us launch;
+// requesting them ahead of the main loop, beside the LDS-DMA, makes the compiler's vmcnt waits cover the DMA as well:
+// +13 .. +44 us on the same launch).
+template <int MI>
+__device__ __forceinline__ void lnf_rows_mean_rstd(const sdmi_gemm_args& p, int64_t mrow0, int fq, float (&mean)[MI],
+                                                   float (&rstd)[MI]) {
+    const int slots = p.ln_stats_slots;
+    const bool paired = (slots & 1) == 0;
+    const int units = paired ? slots >> 1 : slots;      // (odd counts: host-checked <= 4, one 8-byte load per lane)
+    float s1[MI], s2[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) s1[mi] = s2[mi] = 0.f;
+#pragma unroll
+    for (int batch = 0; batch < 2; ++batch) {
+        if (batch * 8 >= units) break;                  // (uniform)
+        f32x4 raw[2][MI];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = batch * 8 + fq + 4 * j;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int64_t m = mrow0 + mi * 16;
+                raw[j][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (u < units && m < p.M) {
+                    if (paired) {
+                        raw[j][mi] = reinterpret_cast<const f32x4*>(p.ln_stats)[m * units + u];
+                    } else {
+                        const f32x2 t = reinterpret_cast<const f32x2*>(p.ln_stats)[m * units + u];
+                        raw[j][mi] = (f32x4){t[0], t[1], 0.f, 0.f};
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                s1[mi] += raw[j][mi][0] + raw[j][mi][2];
+                s2[mi] += raw[j][mi][1] + raw[j][mi][3];
+            }
+    }
+    const float inv_k = 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        lnf_mean_rstd(sum_lane_groups(s1[mi]), sum_lane_groups(s2[mi]), inv_k, p.ln_eps, mean[mi], rstd[mi]);
+    }
+}
+
 // acc <- rstd[m] * (acc - mean[m] * colsum[n]) for the wave's TN x MI accumulator quads; wcol0 = the wave's first weight
 // row + 4 * (lane >> 4)
 template <int TN, int MI>
-__device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], const float (&s1)[MI],
-                                          const float (&s2)[MI], int64_t wcol0, int64_t /*n_w*/) {
-    const float inv_k = 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K);
-    float mean[MI], rstd[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) lnf_mean_rstd(s1[mi], s2[mi], inv_k, p.ln_eps, mean[mi], rstd[mi]);
+__device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], const float (&mean)[MI],
+                                          const float (&rstd)[MI], int64_t wcol0) {
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int64_t wcol = wcol0 + ni * 16;
@@ -202,15 +223,20 @@ __device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[
 // instead of 8 and 32.  P0 = first block of the first pair, chosen by the caller so every pair starts on a 64-byte
 // boundary; blocks left over (TN odd) keep the 8-byte form.  All residual / embedding loads of a row block are
 // requested before the first one is consumed.
+#ifndef SDMI_LNF_DEBUG_NOSTAT
+#define SDMI_LNF_DEBUG_NOSTAT 0   // timing experiment only: the token-stream kernels without the row-statistics stores
+#endif
 #ifndef SDMI_RES_HOIST
 #define SDMI_RES_HOIST 1      // A/B (tools/ab_build.sh): 0 = residual requested row block by row block everywhere
 #endif
-// LNF: the LayerNorm-folded form applied here instead of in place (ln_mean / ln_rstd: the lane's MI rows, LNS floats
-// apart - in LDS for the 256 x 256 x 32 tile, which has no registers for a separate pass over its accumulators).
+// LNF (the instantiations of the transformer blocks' token stream): ln_mean != nullptr - the LayerNorm-folded form applied
+// here instead of in place (ln_mean / ln_rstd: the lane's MI rows, LNS floats apart - in LDS for the 256 x 256 x 32 tile,
+// which has no registers for a separate pass over its accumulators); stat_slot >= 0 - the row sums of the values stored
+// go to p.row_stats_out[m][stat_slot] (the statistics a LayerNorm-folded consumer of this output reads).
 template <int DT, int TN, int MI, int P0, bool HOIST = (SDMI_RES_HOIST != 0), bool LNF = false, int LNS = 1>
 __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], int64_t mrow, int64_t ncol_w,
                                                 int fq, int64_t zoff_out, int64_t zoff_res, const float* ln_mean = nullptr,
-                                                const float* ln_rstd = nullptr) {
+                                                const float* ln_rstd = nullptr, int stat_slot = -1) {
     const int odd = fq & 1;
     const int64_t ncol0 = ncol_w + 4 * fq;                  // own quad inside block 0
     const int64_t ncol8 = ncol_w + odd * 16 + 4 * (fq & 2); // own 8 columns inside pair 0 (after the swap)
@@ -225,8 +251,10 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
     }
     f32x4 csq[LNF ? TN : 1];
     if constexpr (LNF) {
+        if (ln_mean != nullptr) {
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) csq[ni] = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol0 + ni * 16);
+            for (int ni = 0; ni < TN; ++ni) csq[ni] = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol0 + ni * 16);
+        }
     }
     const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
     unsigned short* const outp = reinterpret_cast<unsigned short*>(p.out) + zoff_out;
@@ -287,11 +315,12 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
             }
         }
         uint2 ov[TN];
+        float st1 = 0.f, st2 = 0.f;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             f32x4 v;
-            if constexpr (LNF) v = (acc[ni][mi] - ln_mean[mi * LNS] * csq[ni]) * (ln_rstd[mi * LNS] * p.alpha) + bq[ni];
-            else               v = acc[ni][mi] * p.alpha + bq[ni];
+            if (LNF && ln_mean != nullptr) v = (acc[ni][mi] - ln_mean[mi * LNS] * csq[ni]) * (ln_rstd[mi * LNS] * p.alpha) + bq[ni];
+            else                           v = acc[ni][mi] * p.alpha + bq[ni];
             if (p.act == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
@@ -307,6 +336,21 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
             }
             ov[ni].x = elem_pack2_sel<DT>(v[0], v[1], p.out_f16);
             ov[ni].y = elem_pack2_sel<DT>(v[2], v[3], p.out_f16);
+            if constexpr (LNF) {      // (columns past N hold exact zeros: zero weight rows, no bias / residual read)
+                st1 += (v[0] + v[1]) + (v[2] + v[3]);
+                st2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+        if constexpr (LNF) {
+            if (stat_slot >= 0 && !SDMI_LNF_DEBUG_NOSTAT) {     // (wave-uniform) the four lane groups hold different columns of the same row
+                st1 = sum_lane_groups(st1);
+                st2 = sum_lane_groups(st2);
+                if (fq == 0 && mval) {
+                    f32x2* const so = reinterpret_cast<f32x2*>(p.row_stats_out);
+                    so[m * p.row_stats_slots + stat_slot] = (f32x2){st1, st2};
+                    if (p.dup_rows) so[(m + p.M) * p.row_stats_slots + stat_slot] = (f32x2){st1, st2};
+                }
+            }
         }
 #pragma unroll
         for (int ni = P0; ni + 1 < TN; ni += 2) {
@@ -339,7 +383,7 @@ __device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 
                                                  int fq, const float* ln_mean = nullptr, const float* ln_rstd = nullptr) {
     f32x4 bv[2], bg[2];
     f32x4 cv[LNF ? 2 : 1], cg[LNF ? 2 : 1];
-    if constexpr (LNF) {
+    if constexpr (LNF) {      // (the LNF GEGLU epilogue is only entered with a folded LayerNorm)
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
             cv[pi] = *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol_w + pi * 32 + 4 * fq);
@@ -388,7 +432,8 @@ __device__ __forceinline__ void epilogue_geglu16(const sdmi_gemm_args& p, f32x4 
 // 3-stage LDS ring fed by LDS-DMA with counted vmcnt waits and one barrier per k-tile.
 // (the 2-stage variant: two workgroups per CU).  The second __launch_bounds__ argument is waves per SIMD in HIP, not
 // blocks per CU: 4 caps the 2-stage variant at 128 VGPRs so that two of its workgroups really fit.
-// LNF: the LayerNorm-folded form (ln_colsum; mode 0, f16) - its own instantiations, so no other launch carries the sums.
+// LNF: the instantiations that consume a folded LayerNorm (ln_colsum + ln_stats) and / or emit row statistics
+// (row_stats_out); mode 0, f16 - their own, so no other launch carries the extra epilogue registers.
 template <int MODE, int DT, int TN, int MI, int NST, bool LNF = false>
 __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const sdmi_gemm_args p) {
     constexpr int BM = 64 * MI;                 // 4 waves across M, MI 16-row blocks each
@@ -601,9 +646,6 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     // share of tile t+3 into the stage tile t just vacated, reads the second half of tile t+1 and runs its
     // first-half MFMAs.  Ring: tile t+1 being read, t+2 landed or landing, t+3 in flight.
     uint4 af0[MI], wf0[TN], af1[MI], wf1[TN];
-    float ln_s1[MI], ln_s2[MI];      // LNF: this lane's share of sum(a), sum(a^2) of its MI rows
-#pragma unroll
-    for (int i = 0; i < MI; ++i) ln_s1[i] = ln_s2[i] = 0.f;
 #define SDMI_READ_FRAGS(AF, WF, STAGE, KS)                                                                 \
     do {                                                                                                   \
         const uint4* St_ = lds + (STAGE) * STAGE_CHUNKS;                                                   \
@@ -619,21 +661,6 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 acc[ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[ni_][mi_]);                               \
         if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                   \
     } while (0)
-    // LNF: the row sums of the half k-tile whose MFMAs were just issued.  SDMI_LNF_SPLIT: each wave column takes one of the
-    // two halves of every k-tile (both read the same A fragments), half the VALU work per wave
-#ifndef SDMI_LNF_SPLIT
-#define SDMI_LNF_SPLIT 0
-#endif
-#ifndef SDMI_LNF_VALU_GROUP
-#define SDMI_LNF_VALU_GROUP 0
-#endif
-    const int wn_u = __builtin_amdgcn_readfirstlane(wid) & 1;
-#define SDMI_LNF_ACC(AF, KS)                                                                               \
-    do {                                                                                                   \
-        if constexpr (LNF) {                                                                               \
-            if (!SDMI_LNF_SPLIT || wn_u == (KS)) lnf_accumulate<MI>(AF, ln_s1, ln_s2);                     \
-        }                                                                                                  \
-    } while (0)
 
     // scheduling hint for the region just written: one ds_read, then two MFMAs, MI+TN times (spreads the LDS reads
     // of the next half under the MFMAs of this one instead of bunching them)
@@ -643,8 +670,6 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         _Pragma("unroll") for (int g_ = 0; g_ < MI + TN; ++g_) {                                           \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                             \
-            if constexpr (LNF && SDMI_LNF_VALU_GROUP > 0)                                                  \
-                __builtin_amdgcn_sched_group_barrier(0x002, SDMI_LNF_VALU_GROUP, 0);                       \
         }                                                                                                  \
     } while (0)
 #else
@@ -665,67 +690,35 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         SDMI_READ_FRAGS(af0, wf0, 0, 0);
         SDMI_READ_FRAGS(af1, wf1, 0, 1);
         SDMI_MFMA_HALF(af0, wf0);
-        SDMI_LNF_ACC(af0, 0);
         int rd = 1, wr = 0;                          // ring stage of tile kt+1 / of tile kt (free after the barrier)
         for (int kt = 0; kt + 1 < nk; ++kt) {
             SDMI_WAIT_DMA(kt_issue - kt - 2);        // tile kt+1 landed; younger tiles may still fly
             __syncthreads();                         // every wave has finished READING tile kt as well
             SDMI_READ_FRAGS(af0, wf0, rd, 0);
             SDMI_MFMA_HALF(af1, wf1);                // second half of tile kt
-            if (SDMI_LNF_VALU_GROUP > 0) SDMI_LNF_ACC(af1, 1);
             SDMI_INTERLEAVE();
-            if (SDMI_LNF_VALU_GROUP == 0) SDMI_LNF_ACC(af1, 1);
             if (kt_issue < nk) {
                 SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
                 ++kt_issue;
             }
             SDMI_READ_FRAGS(af1, wf1, rd, 1);
             SDMI_MFMA_HALF(af0, wf0);                // first half of tile kt+1
-            if (SDMI_LNF_VALU_GROUP > 0) SDMI_LNF_ACC(af0, 0);
             SDMI_INTERLEAVE();
-            if (SDMI_LNF_VALU_GROUP == 0) SDMI_LNF_ACC(af0, 0);
             wr = rd;
             rd = rd == NST - 1 ? 0 : rd + 1;
         }
         SDMI_MFMA_HALF(af1, wf1);                    // second half of the last tile
-        SDMI_LNF_ACC(af1, 1);
     }
 
     // ---- epilogue ----
     // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*16*MI + mi*16 + (lane&15),
     // weight row (column of out) wcol = n0 + wn*16*TN + ni*16 + 4*(lane>>4) + j.
     if constexpr (LNF) {
-        lnf_row_totals<MI>(ln_s1, ln_s2);
-        if (SDMI_LNF_SPLIT) {
-            // each wave column holds the sums of its halves of the k-tiles: add the other column's through LDS (the ring is
-            // idle once every wave is past its last fragment read)
-            f32x2* const xs = reinterpret_cast<f32x2*>(smem);
-            __syncthreads();
-            if (fq == 0) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) xs[wn * BM + wm * (MI * 16) + mi * 16 + frow] = (f32x2){ln_s1[mi], ln_s2[mi]};
-            }
-            __syncthreads();
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const f32x2 o = xs[(wn ^ 1) * BM + wm * (MI * 16) + mi * 16 + frow];
-                ln_s1[mi] += o[0];
-                ln_s2[mi] += o[1];
-            }
-        }
-        if (p.split_k > 1) {
-            // this slice's row sums, behind the slabs: [split][M][2]; one column tile and one wave column write them
-            if (tc.tn == 0 && wn == 0 && fq == 0) {
-                float* st = reinterpret_cast<float*>(p.workspace) + (int64_t)p.split_k * p.M * ((int64_t)tiles_n * BN) +
-                            (int64_t)z * p.M * 2;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int64_t m = m0 + wm * (MI * 16) + mi * 16 + frow;
-                    if (m < p.M) *reinterpret_cast<f32x2*>(st + 2 * m) = (f32x2){ln_s1[mi], ln_s2[mi]};
-                }
-            }
-        } else {
-            lnf_apply<TN, MI>(p, acc, ln_s1, ln_s2, n0 + wn * (TN * 16) + 4 * fq, n_w);
+        // the folded LayerNorm, from the producer's row statistics (split-K: the reduce pass applies it)
+        if (p.ln_colsum != nullptr && p.split_k <= 1) {
+            float mean[MI], rstd[MI];
+            lnf_rows_mean_rstd<MI>(p, m0 + wm * (MI * 16) + frow, fq, mean, rstd);
+            lnf_apply<TN, MI>(p, acc, mean, rstd, n0 + wn * (TN * 16) + 4 * fq);
         }
     }
     if (p.split_k > 1) {
@@ -752,8 +745,10 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)(2 * zoff_out) | (uintptr_t)(2 * zoff_res)) & 15) == 0) {
         const int64_t mrow = m0 + wm * (MI * 16) + frow, ncol_w = n0 + wn * (TN * 16);
         // pairs start on even 16-column blocks of the output: with 5 blocks per wave the odd wave column shifts by one
-        if ((TN & 1) && (wn & 1)) epilogue_rows16<DT, TN, MI, 1, (SDMI_RES_HOIST != 0) && NST != 2>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
-        else                      epilogue_rows16<DT, TN, MI, 0, (SDMI_RES_HOIST != 0) && NST != 2>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res);
+        // (LNF: the row sums of what is stored, one slot per column tile and wave column - sdmi_gemm_args.row_stats_out)
+        const int slot = (LNF && p.row_stats_out != nullptr) ? tc.tn * 2 + wn : -1;
+        if ((TN & 1) && (wn & 1)) epilogue_rows16<DT, TN, MI, 1, (SDMI_RES_HOIST != 0) && NST != 2, LNF>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res, nullptr, nullptr, slot);
+        else                      epilogue_rows16<DT, TN, MI, 0, (SDMI_RES_HOIST != 0) && NST != 2, LNF>(p, acc, mrow, ncol_w, fq, zoff_out, zoff_res, nullptr, nullptr, slot);
         return;
     }
     if (!p.geglu && p.out_kind != 2 && (p.N & 3) == 0 && !p.bias_per_row && !p.res_f32) {
@@ -930,7 +925,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                            lds_bytes(wide ? 5 : 4, variant == 1 ? 4 : 2, variant == 2 ? 2 : 3), s, p);              \
     }
 
-// The LayerNorm-folded instantiations (mode 0, f16; 128- and 256-row tiles, three stages).
+// The token-stream instantiations (LNF: folded LayerNorm in, row statistics out; mode 0, f16; 128- and 256-row tiles, three stages).
 #define SDMI_GEMM_UNIT_LNF(NAME)                                                                                    \
     namespace {                                                                                                     \
     typedef void (*lnf_kern_t)(const sdmi_gemm_args);                                                               \

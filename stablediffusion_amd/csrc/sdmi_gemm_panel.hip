@@ -24,7 +24,7 @@ const PanelVariant k320[2][3] = {SDMI_PANEL_SET(0), SDMI_PANEL_SET(1)};
 static bool panel_applies(const sdmi_gemm_args& p) {
     if (p.dtype != SDMI_DTYPE_BF16 && p.dtype != SDMI_DTYPE_F16) return false;
     if (p.A == nullptr || p.W == nullptr || p.out == nullptr || p.algo == 1) return false;
-    if (p.mode != 0 || p.batch > 1 || p.split_k > 1 || p.A2 != nullptr || p.ln_colsum != nullptr || p.emb != nullptr || p.bias_per_row || p.res_f32 ||
+    if (p.mode != 0 || p.batch > 1 || p.split_k > 1 || p.A2 != nullptr || p.ln_colsum != nullptr || p.row_stats_out != nullptr || p.emb != nullptr || p.bias_per_row || p.res_f32 ||
         p.out_kind != 0 || (p.k_valid != 0 && p.k_valid != p.K))
         return false;
     if (p.K != 320 || p.M < 16384) return false;      // fewer rows do not fill the chip with 64 / 128-row panels

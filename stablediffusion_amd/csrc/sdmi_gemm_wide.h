@@ -24,9 +24,6 @@ constexpr int WBK = 32, WBM = 256, WBN = 256, WNST = 4;
 constexpr int WIDE_STAGE_CHUNKS = (WBM + WBN) * (WBK / 8);      // 2048 x 16 B
 constexpr int WIDE_LDS_BYTES = WNST * WIDE_STAGE_CHUNKS * 16;   // 131072
 
-#ifndef SDMI_LNF_DEBUG
-#define SDMI_LNF_DEBUG 0      // timing experiments only (results wrong): 1 = no row sums in the main loop, 2 = plain epilogues
-#endif
 template <int MODE, int DT, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_args p) {
     constexpr int TN = 8, MI = 4, NA = 2;      // (NA = NW = 2 block-wide DMA instructions of 128 rows per operand)
@@ -151,12 +148,6 @@ __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_
     const int nk = kt_end - kt_begin;
 
     uint4 afE[MI], afO[MI], wfL[4], wfH[4];
-    // LNF (sdmi_gemm_kernel.h): row sums of the raw A operand - sum(a) in the waves of column 0, sum(a^2) in column 1 (both
-    // read the same A fragments; the tile has no registers for both sums in one wave), exchanged through LDS at the end
-    float ln_s[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) ln_s[i] = 0.f;
-    const bool ln_squares = (__builtin_amdgcn_readfirstlane(wid) & 1) != 0;      // (wave-uniform, kept in an SGPR)
 #define SDMI_W_READ_A(AF, STAGE)                                                                           \
     do {                                                                                                   \
         const uint4* St_ = lds + (STAGE) * WIDE_STAGE_CHUNKS;                                              \
@@ -172,7 +163,6 @@ __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_
         _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_)                                                \
             _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
                 acc[(HALF) * 4 + ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[(HALF) * 4 + ni_][mi_]);     \
-        if constexpr (LNF && (HALF) == 0 && !(SDMI_LNF_DEBUG & 1)) lnf_accumulate_one<MI>(AF, ln_s, ln_squares); \
     } while (0)
 #ifndef SDMI_WIDE_SCHED
 #define SDMI_WIDE_SCHED 1
@@ -250,54 +240,39 @@ __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_
 #undef SDMI_W_TAP_PTR
 
     // ---- epilogue: acc[ni][mi][j] = row m0 + wm*64 + mi*16 + (lane & 15), weight row n0 + wn*128 + ni*16 + 4*(lane >> 4) + j
-    if constexpr (LNF && !(SDMI_LNF_DEBUG & 2)) {
-        // lane-group totals, then the two wave columns swap sums through LDS (the ring is idle: every DMA has landed and
-        // been read): xs[wn][row of the block tile]
+    if constexpr (LNF) {
+        if (p.split_k <= 1) {
+            // LNF (sdmi_gemm_kernel.h): the token-stream form.  A folded LayerNorm (ln_colsum) is applied inside the 16-bit
+            // epilogues - a separate pass over the 128 accumulator registers spills - from mean / rstd parked in LDS.
+            // For the same reason a residual is requested row block by row block here.  Row statistics out: one slot per
+            // 64-column run (4 per column tile).
+            const bool ln_fold = p.ln_colsum != nullptr;
+            float* const xs = reinterpret_cast<float*>(smem + WIDE_LDS_BYTES);      // [2][256] behind the ring: mean | rstd
+            if (ln_fold) {
+                float mean_r[MI], rstd_r[MI];
+                lnf_rows_mean_rstd<MI>(p, m0 + wm * 64 + frow, fq, mean_r, rstd_r);
+                if (wn == 0 && fq == 0) {      // (both wave columns hold the same rows)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            ln_s[mi] += __shfl_xor(ln_s[mi], 16);
-            ln_s[mi] += __shfl_xor(ln_s[mi], 32);
-        }
-        float* const xs = reinterpret_cast<float*>(smem);
-        __syncthreads();
-        if (fq == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xs[wn * WBM + wm * 64 + mi * 16 + frow] = ln_s[mi];
-        }
-        __syncthreads();
-        if (p.split_k > 1) {
-            if (tc.tn == 0 && wn == 0 && fq == 0) {      // this slice's row sums, behind the slabs: [split][M][2]
-                float* st = reinterpret_cast<float*>(p.workspace) + (int64_t)p.split_k * p.M * ((int64_t)tiles_n * WBN) +
-                            (int64_t)z * p.M * 2;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int r = wm * 64 + mi * 16 + frow;
-                    if (m0 + r < p.M) *reinterpret_cast<f32x2*>(st + 2 * (m0 + r)) = (f32x2){xs[r], xs[WBM + r]};
+                    for (int mi = 0; mi < MI; ++mi) {
+                        xs[wm * 64 + mi * 16 + frow] = mean_r[mi];
+                        xs[WBM + wm * 64 + mi * 16 + frow] = rstd_r[mi];
+                    }
                 }
+                __syncthreads();
             }
-        } else {
-            // mean / rstd of the block's 256 rows, back into LDS: the 16-bit epilogues apply them (a separate pass over the
-            // 128 accumulator registers spills; for the same reason a residual - which no LayerNorm-consuming projection
-            // of the UNet has - is requested row block by row block)
-            if (tid < WBM) {
-                float mean, rstd;
-                lnf_mean_rstd(xs[tid], xs[WBM + tid], 1.0f / (float)(p.k_valid > 0 ? p.k_valid : p.K), p.ln_eps, mean, rstd);
-                xs[2 * WBM + tid] = mean;
-                xs[3 * WBM + tid] = rstd;
-            }
-            __syncthreads();
-            const float* const mean = xs + 2 * WBM + wm * 64 + frow;
-            const float* const rstd = xs + 3 * WBM + wm * 64 + frow;
+            const float* const mean = ln_fold ? xs + wm * 64 + frow : nullptr;
+            const float* const rstd = ln_fold ? xs + WBM + wm * 64 + frow : nullptr;
             typedef f32x4 (&lhalf_t)[4][MI];
             const int64_t mrow = m0 + wm * 64 + frow, ncol = n0 + wn * 128;
-            if (p.geglu) {
+            if (p.geglu) {      // (host-checked: GEGLU comes here only with a folded LayerNorm)
                 epilogue_geglu16<DT, MI, true, 16>(p, reinterpret_cast<lhalf_t>(acc[0]), mrow, ncol, fq, mean, rstd);
                 epilogue_geglu16<DT, MI, true, 16>(p, reinterpret_cast<lhalf_t>(acc[4]), mrow, ncol + 64, fq, mean, rstd);
             } else {
+                const int slot = p.row_stats_out != nullptr ? tc.tn * 4 + wn * 2 : -1;
                 epilogue_rows16<DT, 4, MI, 0, false, true, 16>(p, reinterpret_cast<lhalf_t>(acc[0]), mrow, ncol, fq,
-                                                               zoff_out, zoff_res, mean, rstd);
+                                                               zoff_out, zoff_res, mean, rstd, slot);
                 epilogue_rows16<DT, 4, MI, 0, false, true, 16>(p, reinterpret_cast<lhalf_t>(acc[4]), mrow, ncol + 64, fq,
-                                                               zoff_out, zoff_res, mean, rstd);
+                                                               zoff_out, zoff_res, mean, rstd, slot < 0 ? -1 : slot + 1);
             }
             return;
         }
@@ -347,15 +322,15 @@ __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_
         else           hipLaunchKernelGGL((sdmi_gemm_wide_kernel<1, DT>), grid, dim3(512), WIDE_LDS_BYTES, s, p);   \
     }
 
-// The LayerNorm-folded instantiation (mode 0, f16).
+// The token-stream instantiation (LNF: folded LayerNorm in, row statistics out; mode 0, f16).
 #define SDMI_GEMM_WIDE_UNIT_LNF(NAME)                                                                               \
     int sdmi_gemm_wide_attrs_##NAME() {                                                                             \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(sdmi_gemm_wide_kernel<0, 1, true>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES) != hipSuccess)          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES + 2048) != hipSuccess)   \
             return SDMI_ERR_LAUNCH;                                                                                 \
         return SDMI_OK;                                                                                             \
     }                                                                                                               \
     void sdmi_gemm_wide_launch_##NAME(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {                \
         (void)mode;                                                                                                 \
-        hipLaunchKernelGGL((sdmi_gemm_wide_kernel<0, 1, true>), grid, dim3(512), WIDE_LDS_BYTES, s, p);             \
+        hipLaunchKernelGGL((sdmi_gemm_wide_kernel<0, 1, true>), grid, dim3(512), WIDE_LDS_BYTES + 2048, s, p);      \
     }

@@ -454,6 +454,49 @@ extern "C" int sdmi_groupnorm_noalloc(const void* x1, const void* x2, int32_t C1
     return groupnorm_launch(x1, x2, C1, C2, gamma, beta, out, nb, hw, eps, silu, dtype, ptr, stream);
 }
 
+namespace {
+
+// (sum, sum of squares) of every row: one wave per row, 16 bytes per lane and trip.
+template <int DT>
+__global__ __launch_bounds__(256) void row_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ stats,
+                                                        int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned short* xr = x + row * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int v = lane; v < (C >> 3); v += 64) {
+        float f[8];
+        elem_unpack8<DT>(*reinterpret_cast<const uint4*>(xr + v * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s1 += f[j];
+            s2 += f[j] * f[j];
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * row) = (f32x2){s1, s2};
+}
+
+}  // namespace
+
+extern "C" int sdmi_row_stats(const void* x, float* stats, int64_t rows, int32_t C, int32_t dtype, void* stream) {
+    if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16) return SDMI_ERR_BAD_ARG;
+    if (x == nullptr || stats == nullptr || rows <= 0 || C <= 0 || (rows + 3) / 4 > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
+    if (C % 8 != 0) return SDMI_ERR_ALIGNMENT;
+    const unsigned short* xi = reinterpret_cast<const unsigned short*>(x);
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == SDMI_DTYPE_F16) hipLaunchKernelGGL(row_stats_kernel<1>, grid, dim3(256), 0, hs, xi, stats, rows, C);
+    else                         hipLaunchKernelGGL(row_stats_kernel<0>, grid, dim3(256), 0, hs, xi, stats, rows, C);
+    SDMI_CHECK_LAUNCH();
+    return SDMI_OK;
+}
+
 extern "C" int sdmi_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows,
                               int32_t C, float eps, int32_t dtype, void* stream) {
     if (dtype != SDMI_DTYPE_BF16 && dtype != SDMI_DTYPE_F16 && dtype != SDMI_DTYPE_F16_TO_BF16) return SDMI_ERR_BAD_ARG;

@@ -45,6 +45,10 @@ class GemmArgs(C.Structure):
         ("out_f16", C.c_int32), ("res_f16", C.c_int32), ("a_f16", C.c_int32),
         ("dup_rows", C.c_int32),
         ("ln_colsum", C.c_void_p),
+        ("ln_stats", C.c_void_p),
+        ("ln_stats_slots", C.c_int32),
+        ("row_stats_slots", C.c_int32),
+        ("row_stats_out", C.c_void_p),
     ]
 
 
@@ -72,6 +76,8 @@ SIGNATURES = {
     "sdmi_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "sdmi_gemm_panel_applies": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdmi_gemm_wide_applies": (C.c_int, [C.POINTER(GemmArgs)]),
+    "sdmi_gemm_row_stats_slots": (C.c_int32, [C.POINTER(GemmArgs)]),
+    "sdmi_row_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "sdmi_pack_tile_n": (_i32, [_i64, _i32]),
     "sdmi_pack_linear_k": (_i64, [_i64, _i32]),

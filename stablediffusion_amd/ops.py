@@ -115,6 +115,7 @@ class PackedWeight:
         # input and the kernel normalises through two numbers per row
         self.ln_colsum = ln_colsum
         self.ln_eps = ln_eps
+        self.plain = None       # optional twin without the fold (pack_*(keep_plain=True)): fold_applies() picks per launch
 
 
 _SPLIT_PAD = 32       # fp32 mode: plane width padding (6 * 32 = 3 GEMM k-tiles, and a conv tap never straddles a k-tile)
@@ -193,13 +194,36 @@ def _ln_colsum(packed):
     return packed.double().sum(dim=1).float().contiguous()
 
 
-def pack_linear(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None, ln=None):
+# Rows from which a LayerNorm-consuming projection with a plain twin runs UNfolded (tools/bench_lnfold.py, MI355X): the fold
+# costs one exposed round trip for the row statistics per workgroup (2.5-3 us in the epilogue), the LayerNorm launch it
+# saves costs 11-14 us per layer.  The GEGLU projections (the most workgroup rounds per launch) lose from 4096 rows on
+# (16384 x 5120 x 640: 133 us folded, 131 LayerNorm + GEMM; 4096 x 10240 x 1280: 129 / 125), and where the panel kernel
+# carries the LayerNorm itself (K = 320, >= 16384 rows) it beats the fold on the 3 x 320 and GEGLU projections (82 against
+# 88 us, 164 against 185).  Everything else is faster folded at every size (640 x 640 at 16384 rows: 22 against 34 us).
+FOLD_MAX_ROWS_GEGLU = 4096
+FOLD_MAX_ROWS_PANEL = 16384
+
+
+def fold_applies(pw, rows):
+    """Whether linear() runs `pw` in its LayerNorm-folded form on `rows` rows (else: its plain twin + the LayerNorm)."""
+    if pw.ln_colsum is None:
+        return False
+    if pw.plain is None:
+        return True
+    if pw.geglu and rows >= FOLD_MAX_ROWS_GEGLU:
+        return False
+    if pw.k == 320 and rows >= FOLD_MAX_ROWS_PANEL and (pw.geglu or pw.n_out == 960):
+        return False
+    return True
+
+
+def pack_linear(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None, ln=None, keep_plain=False):
     """nn.Linear / conv1x1 weight [N, K(,1,1)] fp32 -> PackedWeight."""
     return pack_linear_cat([weight], None if bias is None else [bias], dtype=dtype, tile_n=tile_n, out_dtype=out_dtype,
-                           ln=ln)
+                           ln=ln, keep_plain=keep_plain)
 
 
-def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=None, ln=None):
+def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=None, ln=None, keep_plain=False):
     """Several [N_i, K] linears sharing an input, fused along N (q|k|v, the 22 emb projections).
     ln = (gamma, beta[, eps]) of the nn.LayerNorm the projection's input goes through: with f16 operands the norm is folded
     into the packed weights (PackedWeight.ln_colsum) and linear() takes the un-normalised input."""
@@ -208,6 +232,7 @@ def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=Non
     k = ws[0].shape[1]
     b = torch.cat([_src(x) for x in biases]).contiguous() if biases is not None else None
     fold = _ln_folds(dtype, ln)
+    plain = pack_linear_cat(weights, biases, dtype=dtype, tile_n=tile_n, out_dtype=out_dtype) if fold and keep_plain else None
     if fold:
         wcat, b = _fold_ln(torch.cat(ws), b, ln)
         ws = [wcat]
@@ -216,12 +241,14 @@ def pack_linear_cat(weights, biases=None, dtype=BF16, tile_n=None, out_dtype=Non
     kp = hip.lib().sdmi_pack_linear_k(k, code)
     out = _pack_alloc(n, kp, tn, tdt, ws[0].device)
     _pack_rows(ws, out, code, tn)
-    return PackedWeight(out, b, n, kp, tile_n=tn, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
-                        out_dtype=out_dtype if dtype != torch.float32 else None,
-                        ln_colsum=_ln_colsum(out) if fold else None, ln_eps=(ln[2] if len(ln) > 2 else 1e-5) if fold else None)
+    pw = PackedWeight(out, b, n, kp, tile_n=tn, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
+                      out_dtype=out_dtype if dtype != torch.float32 else None,
+                      ln_colsum=_ln_colsum(out) if fold else None, ln_eps=(ln[2] if len(ln) > 2 else 1e-5) if fold else None)
+    pw.plain = plain
+    return pw
 
 
-def pack_geglu(weight, bias, dtype=BF16, ln=None):
+def pack_geglu(weight, bias, dtype=BF16, ln=None, keep_plain=False):
     """GEGLU projection [2*inner, K]: rows [0,inner) = value, [inner,2*inner) = gate (attention.py:89).
     Packed row r holds value (half 0) or gate (half 1) column blk*16+i with blk=r//32, half=(r%32)//16, i=r%16.
     ln: as pack_linear_cat."""
@@ -233,6 +260,7 @@ def pack_geglu(weight, bias, dtype=BF16, ln=None):
     out = _pack_alloc(2 * inner, kp, _BN, tdt, w.device)
     b = _src(bias) if bias is not None else None
     fold = _ln_folds(dtype, ln)
+    plain = pack_geglu(weight, bias, dtype=dtype) if fold and keep_plain else None
     if fold:
         w, b = _fold_ln(w, b, ln)
     bo = torch.empty_like(b) if b is not None else None
@@ -241,8 +269,10 @@ def pack_geglu(weight, bias, dtype=BF16, ln=None):
     else:
         st = hip.lib().sdmi_pack_geglu_host(_p(w), _p(b), inner, k, k, _p(out), _p(bo), code)
     hip.check(st, "sdmi_pack_geglu")
-    return PackedWeight(out, bo, inner, kp, geglu=True, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
-                        ln_colsum=_ln_colsum(out) if fold else None, ln_eps=(ln[2] if len(ln) > 2 else 1e-5) if fold else None)
+    pw = PackedWeight(out, bo, inner, kp, geglu=True, split_cp=_round_up(k, _SPLIT_PAD) if dtype == torch.float32 else 0,
+                      ln_colsum=_ln_colsum(out) if fold else None, ln_eps=(ln[2] if len(ln) > 2 else 1e-5) if fold else None)
+    pw.plain = plain
+    return pw
 
 
 def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None):
@@ -458,17 +488,33 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
 FUSE_LN = True      # tests / tools: False runs the LayerNorm of linear(..., ln=...) as its own launch everywhere
 
 
+def row_stats_of(x):
+    """(stats fp32 [rows, 1, 2], 1): per row (sum, sum of squares) of a 16-bit matrix, in the layout a LayerNorm-folded
+    projection reads (sdmi_row_stats) - for inputs that no launch with row_stats=True produced."""
+    c = x.shape[-1]
+    rows = x.numel() // c
+    _require(x, x.dtype, "x")
+    st = torch.empty(rows, 1, 2, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().sdmi_row_stats(_p(x), _p(st), rows, c, _dt(x.dtype), _stream()), "sdmi_row_stats")
+    return st, 1
+
+
 def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_dtype=None, alpha=1.0, bias=True,
-           out_nchw_f32=None, ln=None, dup_rows=False):
+           out_nchw_f32=None, ln=None, dup_rows=False, stats=None, row_stats=False):
     """out[M, N] = epilogue(x[M, K] @ W^T).  x2: second source for the trailing K columns (channel concat).
     ln = (gamma, beta[, eps]): out = epilogue(LayerNorm(x) @ W^T) - fused into the GEMM where the A-panel-stationary
     kernel applies (sdmi_gemm_panel_applies), a sdmi_layernorm launch in front of it elsewhere.
     out_dtype: None = the operand type, or torch.float32.  fp32 mode (pw.split_cp): x (and x2, res) are fp32, the
     input is split into bf16 piece planes first and the output is fp32.
     dup_rows: the output has 2 M rows, rows [M, 2M) a copy of rows [0, M) (sdmi_gemm_args.dup_rows: the guidance-pair
-    duplication of the UNet written by the producing launch)."""
+    duplication of the UNet written by the producing launch).
+    A weight packed behind a LayerNorm (pack_*(ln=...), f16) takes the RAW input plus its row statistics `stats` =
+    (tensor, slots) as a launch with row_stats=True returned them for its output (None: computed here, one more launch).
+    row_stats=True: returns (out, stats) - stats = None where the launch cannot produce them (bf16 / fp32 operands)."""
     if dup_rows and (pw.split_cp or out_nchw_f32 is not None or (out_dtype is not None and out_dtype not in HALF_TYPES)):
         raise hip.SdmiError("linear: dup_rows needs a 16-bit row-major output")
+    if pw.ln_colsum is not None and not fold_applies(pw, x.numel() // x.shape[-1]):
+        pw = pw.plain           # this size runs faster unfolded: the plain twin + the LayerNorm (panel kernel or its own launch)
     if pw.ln_colsum is not None:
         # the LayerNorm lives in the packed weights (pack_*(ln=...)): the kernel takes the raw input
         if ln is None or x2 is not None or emb is not None:
@@ -491,7 +537,13 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     a.lda = k1
     a.M = m
     if pw.ln_colsum is not None:
+        if stats is None:
+            stats = row_stats_of(x)
+        st_t, st_slots = stats
+        if st_t.shape[0] != m or st_t.dtype != torch.float32 or not st_t.is_contiguous():
+            raise hip.SdmiError("linear: row statistics do not match the input's rows")
         a.ln_colsum, a.ln_eps = pw.ln_colsum.data_ptr(), pw.ln_eps
+        a.ln_stats, a.ln_stats_slots = st_t.data_ptr(), st_slots
     if x2 is not None:
         _require(x2, pw.dtype, "x2")
         a.A2 = x2.data_ptr()
@@ -514,6 +566,14 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
         else:
             out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
         keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
+    out_stats = None
+    if row_stats and pw.dtype == F16 and not pw.split_cp and out_nchw_f32 is None and out_dtype == F16 and not pw.geglu \
+            and x2 is None and emb is None:
+        # the row sums of what this launch stores, for the LayerNorm-folded projection that reads it next
+        a.row_stats_slots = hip.lib().sdmi_gemm_row_stats_slots(C.byref(a))
+        st_o = torch.empty(out.numel() // pw.n_out, a.row_stats_slots, 2, dtype=torch.float32, device=x.device)
+        a.row_stats_out = st_o.data_ptr()
+        out_stats = (st_o, int(a.row_stats_slots))
     if ln is not None:
         gamma, beta = ln[0], ln[1]
         _require(gamma, torch.float32, "ln gamma")
@@ -530,7 +590,7 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
             a.A = xn.data_ptr()
     _run_gemm(a, "sdmi_gemm(linear)")
     del keep
-    return out
+    return (out, out_stats) if row_stats else out
 
 
 def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False, asym_pad=False, dup_rows=False):

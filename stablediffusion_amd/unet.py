@@ -149,12 +149,12 @@ def pack_spatial_transformer(st, cd, kv_off=0):
             "ln3": (f32(tb.norm3.weight), f32(tb.norm3.bias)),
             # (ln=: with f16 operands the three LayerNorms are folded into the projections they feed - ops.pack_linear_cat)
             "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd,
-                                        ln=(tb.norm1.weight, tb.norm1.bias, tb.norm1.eps)),
+                                        ln=(tb.norm1.weight, tb.norm1.bias, tb.norm1.eps), keep_plain=c == 320),
             "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd, out_dtype=sd),
             "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd, ln=(tb.norm2.weight, tb.norm2.bias, tb.norm2.eps)),
             "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd, out_dtype=sd),
             "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd,
-                                    ln=(tb.norm3.weight, tb.norm3.bias, tb.norm3.eps)),
+                                    ln=(tb.norm3.weight, tb.norm3.bias, tb.norm3.eps), keep_plain=True),
             "ff2": ops.pack_linear(tb.feed_forward.net[2].weight, tb.feed_forward.net[2].bias, dtype=cd, out_dtype=sd),
             "kv_off": kv_off, "c": c, "heads": tb.attn1.heads, "scale": tb.attn1.scale,
         }
@@ -164,6 +164,13 @@ def pack_spatial_transformer(st, cd, kv_off=0):
         kv_off += 2 * c
         e["blocks"].append(be)
     return e, kv_w, kv_off
+
+
+def _linear_st(x, pw, want_stats, **kw):
+    """ops.linear -> (out, row statistics of out | None)."""
+    if want_stats:
+        return ops.linear(x, pw, row_stats=True, **kw)
+    return ops.linear(x, pw, **kw), None
 
 
 def run_spatial_transformer(e, h, kv, nk, pair_prefix=False):
@@ -181,27 +188,31 @@ def run_spatial_transformer(e, h, kv, nk, pair_prefix=False):
         b //= 2
         h = h[:b]
     xn = ops.groupnorm(h, e["norm"][0], e["norm"][1], 1e-6, False, out_dtype=e["pin"].dtype)
-    t = ops.linear(xn.reshape(b * n, c), e["pin"])
-    for bi, be in enumerate(e["blocks"]):
+    # `st`: the row statistics of the token stream `t`, left by the launch that wrote it (ops.linear(row_stats=True)) for
+    # the LayerNorm-folded projection that reads it next (f16 operands; None elsewhere, and ops.linear ignores it)
+    # (ops.fold_applies: a projection with a plain twin runs unfolded at the sizes where that is faster)
+    blocks = e["blocks"]
+    t, st = _linear_st(xn.reshape(b * n, c), e["pin"], bool(blocks) and ops.fold_applies(blocks[0]["qkv1"], b * n))
+    for bi, be in enumerate(blocks):
         ci, heads = be["c"], be["heads"]
-        qkv = ops.linear(t, be["qkv1"], ln=be["ln1"])
+        qkv = ops.linear(t, be["qkv1"], ln=be["ln1"], stats=st)
         a = ops.attention_d64(qkv[:, :ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:], heads, b, n, n, be["scale"])
         dup = pair_prefix and bi == 0
         # (dup: the output projection of the first self-attention stores every row twice - the duplication of the
         # guidance pairs where the context enters, without a copy kernel)
         if dup and t.dtype not in ops.HALF_TYPES:       # fp32 mode (built for the 1e-5 gate, not for speed): a plain copy
-            t = ops.linear(a, be["o1"], res=t)
+            t, st = ops.linear(a, be["o1"], res=t), None
             t = torch.cat([t, t])
         else:
-            t = ops.linear(a, be["o1"], res=t, dup_rows=dup)
+            t, st = _linear_st(a, be["o1"], ops.fold_applies(be["q2"], b * n * (2 if dup else 1)), res=t, dup_rows=dup)
         if dup:
             h, b = h_full, 2 * b
-        q2 = ops.linear(t, be["q2"], ln=be["ln2"])
+        q2 = ops.linear(t, be["q2"], ln=be["ln2"], stats=st)
         ko = be["kv_off"]
         a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
-        t = ops.linear(a, be["o2"], res=t)
-        g = ops.linear(t, be["geglu"], ln=be["ln3"])
-        t = ops.linear(g, be["ff2"], res=t)
+        t, st = _linear_st(a, be["o2"], ops.fold_applies(be["geglu"], b * n), res=t)
+        g = ops.linear(t, be["geglu"], ln=be["ln3"], stats=st)
+        t, st = _linear_st(g, be["ff2"], bi + 1 < len(blocks) and ops.fold_applies(blocks[bi + 1]["qkv1"], b * n), res=t)
     out = ops.linear(t, e["pout"], res=h.reshape(b * n, c))
     return out.reshape(b, hh, ww, c)
 

@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == set(hip.SIGNATURES), "ctypes binding and header disagree"
     assert lib.sdmi_abi_version() == hip.ABI_VERSION >= 4
     assert b"workspace" in lib.sdmi_status_str(-3) and b"no-allocation" in lib.sdmi_status_str(-5)
-    assert lib.sdmi_gemm_workspace_bytes(128, 1280, 4) == 4 * 128 * (1280 + 2) * 4      # slabs + the row sums of a folded LayerNorm
+    assert lib.sdmi_gemm_workspace_bytes(128, 1280, 4) == 4 * 128 * 1280 * 4
     assert lib.sdmi_gemm_workspace_bytes(128, 1280, 1) == 0
     assert lib.sdmi_groupnorm_workspace_bytes(2, 4096) > 0
 
@@ -407,3 +407,16 @@ def test_narrow_conv_is_never_split(lib):
     a = hip.GemmArgs()
     a.mode, a.H, a.W_in, a.Cin, a.Ho, a.Wo, a.stride, a.M = 1, 64, 64, 320, 64, 64, 1, 8192
     assert not ops._narrow_conv_applies(a, pw2)
+
+
+def test_fold_policy_of_layernorm_consuming_projections():
+    """ops.fold_applies: folded wherever there is no plain twin; with one, the GEGLU projections run unfolded from 4096 rows
+    on and the K = 320 projections the panel kernel serves (3 x 320 columns, GEGLU) from 16384 rows on."""
+    import types
+    from stablediffusion_amd import ops
+    mk = lambda **kw: types.SimpleNamespace(**{"ln_colsum": object(), "plain": object(), "geglu": False, "k": 640, "n_out": 1920, **kw})
+    assert not ops.fold_applies(mk(ln_colsum=None), 128)
+    assert ops.fold_applies(mk(plain=None, geglu=True), 1 << 20)
+    assert ops.fold_applies(mk(geglu=True), 2048) and not ops.fold_applies(mk(geglu=True), 4096)
+    assert ops.fold_applies(mk(k=320, n_out=960), 8192) and not ops.fold_applies(mk(k=320, n_out=960), 16384)
+    assert ops.fold_applies(mk(k=320, n_out=320), 65536) and ops.fold_applies(mk(), 65536)

@@ -731,9 +731,11 @@ def test_fused_layernorm_falls_back_and_refuses(dev):
 ])
 def test_layernorm_folded_into_the_projection(dev, kind, m, k, n, res):
     """pack_*(ln=...) with f16 operands: W * gamma is packed, the kernel multiplies the RAW input and applies
-    rstd * (acc - mean * rowsum(W')) - sdmi_gemm_args.ln_colsum.  Against torch in fp32 (LayerNorm of attention.py:512-514
-    + the projection), and against the unfolded path (sdmi_layernorm / the panel kernel + the same GEMM): the folded form
-    drops the f16 rounding of the normalised operand, so it must not be further from fp32 than the unfolded one."""
+    rstd * (acc - mean * rowsum(W')) from the input's row statistics - sdmi_gemm_args.ln_colsum / ln_stats (here from
+    sdmi_row_stats, which ops.linear runs when no producer handed them over).  Against torch in fp32 (LayerNorm of
+    attention.py:512-514 + the projection), and against the unfolded path (sdmi_layernorm / the panel kernel + the same
+    GEMM): the folded form drops the f16 rounding of the normalised operand, so it must not be further from fp32 than the
+    unfolded one."""
     ops = _ops()
     qd = lambda t: t.to(F16).float()
     # rows with different means and scales, a residual-stream-like input
@@ -763,6 +765,48 @@ def test_layernorm_folded_into_the_projection(dev, kind, m, k, n, res):
         ops.linear(x, folded)                       # a folded weight needs the caller to say it knows (ln=...)
 
 
+@pytest.mark.parametrize("m,k,n,res,dup", [
+    (300, 320, 320, True, False),          # 128-row tiles, ragged rows: 2 column tiles x 2 wave columns = 4 slots
+    (16384, 320, 320, True, True),         # 256-row tiles + the duplicated store of the guidance-pair prefix
+    (2100, 2560, 640, True, False),
+    (256, 5120, 1280, True, False),        # split-K: the row-wise reduce pass writes one slot
+    (8192, 1280, 1280, False, False),      # the 256 x 256 x 32 tile: one slot per 64-column run
+])
+def test_row_statistics_travel_with_the_token_stream(dev, m, k, n, res, dup):
+    """ops.linear(row_stats=True): the launch that writes the residual stream leaves per row and slot the partial
+    (sum, sum of squares) of what it stores - sdmi_gemm_args.row_stats_out; the LayerNorm-folded projection that reads the
+    stream next takes them instead of normalising (or re-reading) its input.  Checked: the slots add up to the sums of the
+    stored rows, and the consumer's output equals the one computed from sdmi_row_stats of the same input."""
+    ops = _ops()
+    x0 = rnd((m, k), dev, 71).to(F16)
+    w0, b0 = rnd((n, k), dev, 72, 0.05), rnd((n,), dev, 73)
+    r = (rnd((m, n), dev, 74) * 2.0 + 0.7).to(F16) if res else None
+    prod = ops.pack_linear(w0, b0, dtype=F16)
+    t, (st, slots) = ops.linear(x0, prod, res=r, dup_rows=dup, row_stats=True)
+    plain = ops.linear(x0, prod, res=r, dup_rows=dup)
+    assert torch.equal(t, plain)                                   # the statistics change nothing in the output
+    rows = 2 * m if dup else m
+    assert st.shape == (rows, slots, 2) and t.shape == (rows, n)
+    tot = st.double().sum(dim=1)
+    tf = t.double()
+    # (sums of the fp32 values before their rounding to f16: equal to the stored rows' up to that rounding)
+    assert (tot[:, 0] - tf.sum(1)).abs().max() < 2e-3 * tf.abs().sum(1).max()
+    assert (tot[:, 1] - (tf * tf).sum(1)).abs().max() < 2e-3 * (tf * tf).sum(1).max()
+    if dup:
+        assert torch.equal(st[:m], st[m:])
+    gamma, beta = 1.0 + 0.2 * rnd((n,), dev, 75), 0.3 * rnd((n,), dev, 76)
+    ln = (gamma, beta, 1e-5)
+    w1 = rnd((3 * n, n), dev, 77, 0.05)
+    cons = ops.pack_linear(w1, dtype=F16, ln=ln)
+    out = ops.linear(t, cons, ln=ln, stats=(st, slots))
+    out2 = ops.linear(t, cons, ln=ln)                               # statistics recomputed from the stored rows
+    ref = F.linear(F.layer_norm(t.float(), (n,), gamma, beta, 1e-5), w1)
+    assert rel_err(out, ref) < 1.5e-3 and rel_err(out2, ref) < 1.5e-3
+    assert rel_err(out, out2.float()) < 1.2e-3                       # (one f16 rounding step of the largest output)
+    with pytest.raises(ops.hip.SdmiError):
+        ops.linear(t[:-1], cons, ln=ln, stats=(st, slots))          # statistics of other rows
+
+
 def test_layernorm_fold_is_f16_only_and_checked(dev):
     ops = _ops()
     gamma, beta = 1.0 + 0.2 * rnd((320,), dev, 63), 0.3 * rnd((320,), dev, 64)
@@ -775,6 +819,9 @@ def test_layernorm_fold_is_f16_only_and_checked(dev):
     a.mode, a.A, a.lda, a.M, a.W, a.N, a.K = 0, x.data_ptr(), 320, 256, pw.w.data_ptr(), 320, 320
     a.out, a.ld_out, a.dtype, a.tile_n, a.alpha, a.batch, a.split_k = o.data_ptr(), 320, 1, pw.tile_n, 1.0, 1, 1
     a.ln_colsum, a.ln_eps = pw.ln_colsum.data_ptr(), 1e-5
+    assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # no row statistics
+    st, slots = ops.row_stats_of(x)
+    a.ln_stats, a.ln_stats_slots = st.data_ptr(), slots
     assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == 0
     a.dtype = 0
     assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == -1          # bf16 operands

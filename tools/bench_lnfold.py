@@ -40,9 +40,26 @@ for kind, m, n, k in SHAPES:
     else:
         w = (torch.randn(n, k, generator=g) * 0.05).to(dev)
         folded, plain = ops.pack_linear(w, None, dtype=F16, ln=ln), ops.pack_linear(w, None, dtype=F16)
+    # the statistics as the model has them: left by the launch that produced the input (slot count of a K -> K projection)
+    prod = ops.pack_linear((torch.randn(k, k, generator=g) * k ** -0.5).to(dev), None, dtype=F16)
+    pairs = [ops.linear(x, prod, row_stats=True) for x in xs]
+    xs, sts = [p_[0] for p_ in pairs], [p_[1] for p_ in pairs]
     t_f = t_u = t_b = 1e9
     for _ in range(3):          # round-robin, best of three: the first timed loop after an idle phase reads slow
         t_b = min(t_b, timed(lambda i: ops.linear(xs[i % ROT], plain)))
-        t_f = min(t_f, timed(lambda i: ops.linear(xs[i % ROT], folded, ln=ln)))
+        t_f = min(t_f, timed(lambda i: ops.linear(xs[i % ROT], folded, ln=ln, stats=sts[i % ROT])))
         t_u = min(t_u, timed(lambda i: ops.linear(xs[i % ROT], plain, ln=ln)))
-    print(f"{kind:6s} M {m:6d} N {n:5d} K {k:5d}: folded {t_f:7.1f} us   unfolded (LN + GEMM) {t_u:7.1f}   bare GEMM {t_b:7.1f}", flush=True)
+    print(f"{kind:6s} M {m:6d} N {n:5d} K {k:5d} slots {sts[0][1]:2d}: folded {t_f:7.1f} us   unfolded (LN + GEMM) {t_u:7.1f}   bare GEMM {t_b:7.1f}", flush=True)
+
+# the producers of the stream: to_out / proj_in (K = C) and ff2 (K = 4 C) with the residual, with and without row_stats
+for m, c in zip(rows, (320, 640, 1280, 1280)):
+    for k in (c, 4 * c):
+        g = torch.Generator(device="cpu").manual_seed(2)
+        xs = [torch.randn(m, k, generator=g).to(dev).to(F16) for _ in range(ROT)]
+        rs = [torch.randn(m, c, generator=g).to(dev).to(F16) for _ in range(ROT)]
+        pw = ops.pack_linear((torch.randn(c, k, generator=g) * 0.05).to(dev), torch.randn(c, generator=g).to(dev), dtype=F16)
+        t_p = t_s = 1e9
+        for _ in range(3):
+            t_p = min(t_p, timed(lambda i: ops.linear(xs[i % ROT], pw, res=rs[i % ROT])))
+            t_s = min(t_s, timed(lambda i: ops.linear(xs[i % ROT], pw, res=rs[i % ROT], row_stats=True)))
+        print(f"producer M {m:6d} N {c:5d} K {k:5d}: plain {t_p:7.1f} us   with row_stats {t_s:7.1f}", flush=True)
