@@ -420,3 +420,28 @@ def test_fold_policy_of_layernorm_consuming_projections():
     assert ops.fold_applies(mk(geglu=True), 2048) and not ops.fold_applies(mk(geglu=True), 4096)
     assert ops.fold_applies(mk(k=320, n_out=960), 8192) and not ops.fold_applies(mk(k=320, n_out=960), 16384)
     assert ops.fold_applies(mk(k=320, n_out=320), 65536) and ops.fold_applies(mk(), 65536)
+
+
+def test_layernorm_fold_algebra_of_the_packers():
+    """ops._fold_ln / _ln_colsum (host side of sdmi_gemm_args.ln_colsum): LayerNorm(x) @ W^T + b equals
+    rstd * (x @ W'^T - mean * rowsum(W')) + b' with W' = W * gamma and b' = b + W @ beta - here in fp64 with the row
+    statistics taken as (sum, sum of squares), which is what the kernels receive."""
+    import torch
+    import torch.nn.functional as F
+    from stablediffusion_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(37, 320, generator=g) * 2.0 + 0.8).double()
+    w, b = torch.randn(96, 320, generator=g) * 0.05, torch.randn(96, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(320, generator=g), 0.3 * torch.randn(320, generator=g)
+    wf, bf = ops._fold_ln(w, b, (gamma, beta, 1e-5))
+    colsum = ops._ln_colsum(wf)
+    s1, s2 = x.sum(1), (x * x).sum(1)
+    mean = s1 / 320
+    rstd = (s2 / 320 - mean * mean + 1e-5).rsqrt()
+    folded = rstd[:, None] * (x @ wf.double().T - mean[:, None] * colsum.double()[None, :]) + bf.double()
+    ref = F.linear(F.layer_norm(x, (320,), gamma.double(), beta.double(), 1e-5), w.double(), b.double())
+    assert (folded - ref).abs().max() < 1e-5 * ref.abs().max()
+    # no bias: the folded layer still gets one (W @ beta)
+    wf2, bf2 = ops._fold_ln(w, None, (gamma, beta))
+    assert torch.equal(wf2, wf) and torch.allclose(bf2, bf - b, atol=1e-6)
+
