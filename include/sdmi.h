@@ -45,7 +45,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 12: + sdmi_gemm_args.ln_colsum / ln_stats / row_stats_out (LayerNorm folded into the projection, row statistics travelling with the residual stream), sdmi_gemm_row_stats_slots, sdmi_row_stats; 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 12: + sdmi_gemm_args.ln_colsum / ln_stats / row_stats_out (LayerNorm folded into the projection, row statistics travelling with the residual stream), sdmi_gemm_row_stats_slots, sdmi_row_stats, sdmi_xattn_block (the cross-attention half of a transformer block as one launch); 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -173,6 +173,33 @@ int sdmi_row_stats(const void* x, float* stats, int64_t rows, int32_t C, int32_t
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
 /* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);
+
+/* ------------------------------------------------------------------------------------------
+ * The cross-attention half of a BasicTransformerBlock as one launch (C = 320, 5 heads of 64: level 0 of the SD2 UNet):
+ *     out = to_out( softmax( scale * to_q(LayerNorm(x)) K^T ) V ) + bias_o + x
+ * Replaces the chain norm2 -> attn2.to_q -> CrossAttention.forward -> attn2.to_out[0] + residual at attention.py:518-528
+ * (CrossAttention: attention.py:300-380) - three launches and two round trips of a [tokens, C] tensor - for a context of
+ * up to 128 keys.  Every step is local to a token row except the read of the prompt's keys / values, so a workgroup runs
+ * the chain on 128 rows resident in LDS.  x, out: f16 [M, ld]; wq, wo: f16 [320][320] as sdmi_pack_linear packs them with
+ * tile_n = 160 (PLAIN weights: the LayerNorm is computed on the resident rows, exact two-pass statistics); k, v: f16
+ * [images * nk, ld] (image b's keys at rows b * nk ...), head h at columns h * 64; rows_per_image = tokens of one image.
+ * row_stats_out (optional, row_stats_slots = 4): as sdmi_gemm_args.row_stats_out, for a LayerNorm-folded consumer of `out`.
+ * sdmi_xattn_block_applies() == 1 iff the problem fits: dtype SDMI_DTYPE_F16, C == 320, heads == 5, nk <= 128, M and
+ * rows_per_image multiples of 128, 16-byte aligned pointers, leading dimensions % 8 == 0. */
+typedef struct sdmi_xattn_args {
+    const void* x; int64_t ldx;
+    int64_t M; int32_t rows_per_image;
+    int32_t C, heads;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void* wq; const void* wo; const float* bias_o;
+    const void* k; const void* v; int64_t ldk, ldv; int32_t nk;
+    float scale;
+    void* out; int64_t ld_out;
+    float* row_stats_out; int32_t row_stats_slots;
+    int32_t dtype;
+} sdmi_xattn_args;
+int sdmi_xattn_block(const sdmi_xattn_args* args, void* stream);
+int sdmi_xattn_block_applies(const sdmi_xattn_args* args);
 
 /* ------------------------------------------------------------------------------------------
  * Weight packing: fp32 weights in the reference's own (PyTorch state-dict) layout -> the pre-packed W operand that

@@ -233,10 +233,14 @@ __device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[
 // here instead of in place (ln_mean / ln_rstd: the lane's MI rows, LNS floats apart - in LDS for the 256 x 256 x 32 tile,
 // which has no registers for a separate pass over its accumulators); stat_slot >= 0 - the row sums of the values stored
 // go to p.row_stats_out[m][stat_slot] (the statistics a LayerNorm-folded consumer of this output reads).
-template <int DT, int TN, int MI, int P0, bool HOIST = (SDMI_RES_HOIST != 0), bool LNF = false, int LNS = 1>
+// PRE (sdmi_xattn.hip, one resident workgroup per CU - nobody to hide the trip behind): bias and residual were requested
+// ahead of the main loop by epilogue_rows16_prefetch (same template arguments, same lane -> element map) and arrive in
+// pre_bias / pre_res.
+template <int DT, int TN, int MI, int P0, bool HOIST = (SDMI_RES_HOIST != 0), bool LNF = false, int LNS = 1, bool PRE = false>
 __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (&acc)[TN][MI], int64_t mrow, int64_t ncol_w,
                                                 int fq, int64_t zoff_out, int64_t zoff_res, const float* ln_mean = nullptr,
-                                                const float* ln_rstd = nullptr, int stat_slot = -1) {
+                                                const float* ln_rstd = nullptr, int stat_slot = -1,
+                                                const f32x4* pre_bias = nullptr, const uint2 (*pre_res)[TN] = nullptr) {
     const int odd = fq & 1;
     const int64_t ncol0 = ncol_w + 4 * fq;                  // own quad inside block 0
     const int64_t ncol8 = ncol_w + odd * 16 + 4 * (fq & 2); // own 8 columns inside pair 0 (after the swap)
@@ -247,7 +251,8 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
         const int64_t n = ncol0 + ni * 16;
         nval[ni] = n < p.N;
         bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if constexpr (PRE) bq[ni] = pre_bias[ni];
+        else if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
     }
     f32x4 csq[LNF ? TN : 1];
     if constexpr (LNF) {
@@ -284,7 +289,12 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
                 rq_all[mi][ni] = *reinterpret_cast<const uint2*>(resp + m * p.ld_res + ncol0 + ni * 16);   \
         }                                                                                                  \
     } while (0)
-    if (HOIST && p.res != nullptr) {
+    if constexpr (PRE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) rq_all[mi][ni] = pre_res[mi][ni];
+    } else if (HOIST && p.res != nullptr) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) SDMI_RES_LOAD_ROWBLOCK(mi);
     }
@@ -295,7 +305,7 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
         uint2 rq[TN];
         f32x4 eq[TN];
         if (p.res != nullptr) {
-            if (!HOIST) SDMI_RES_LOAD_ROWBLOCK(mi);
+            if (!HOIST && !PRE) SDMI_RES_LOAD_ROWBLOCK(mi);
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) rq[ni] = rq_all[mi][ni];
 #pragma unroll
@@ -371,6 +381,27 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
             }
         }
     }
+}
+
+// The loads of epilogue_rows16<..., PRE = true>: column bias and residual of the wave's tile, in the epilogue's own lane ->
+// element map (p.bias and p.res must be set).
+template <int DT, int TN, int MI, int P0>
+__device__ __forceinline__ void epilogue_rows16_prefetch(const sdmi_gemm_args& p, int64_t mrow, int64_t ncol_w, int fq,
+                                                         int64_t zoff_res, f32x4 (&bq)[TN], uint2 (&rq_all)[MI][TN]) {
+    const int odd = fq & 1;
+    const int64_t ncol0 = ncol_w + 4 * fq;
+    const int64_t ncol8 = ncol_w + odd * 16 + 4 * (fq & 2);
+    bool nval[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int64_t n = ncol0 + ni * 16;
+        nval[ni] = n < p.N;
+        bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+    const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) SDMI_RES_LOAD_ROWBLOCK(mi);
 }
 
 #undef SDMI_RES_LOAD_ROWBLOCK

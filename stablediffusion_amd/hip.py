@@ -56,6 +56,21 @@ ABI_VERSION = 12    # sdmi_abi_version() of the library this binding was written
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
+
+class XattnArgs(C.Structure):
+    """sdmi_xattn_args (include/sdmi.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int64), ("rows_per_image", C.c_int32),
+        ("C", C.c_int32), ("heads", C.c_int32),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("wq", C.c_void_p), ("wo", C.c_void_p), ("bias_o", C.c_void_p),
+        ("k", C.c_void_p), ("v", C.c_void_p), ("ldk", C.c_int64), ("ldv", C.c_int64), ("nk", C.c_int32),
+        ("scale", C.c_float),
+        ("out", C.c_void_p), ("ld_out", C.c_int64),
+        ("row_stats_out", C.c_void_p), ("row_stats_slots", C.c_int32),
+        ("dtype", C.c_int32),
+    ]
+
 # name -> (restype, argtypes); every symbol include/sdmi.h declares
 SIGNATURES = {
     "sdmi_status_str": (C.c_char_p, [C.c_int]),
@@ -78,6 +93,8 @@ SIGNATURES = {
     "sdmi_gemm_wide_applies": (C.c_int, [C.POINTER(GemmArgs)]),
     "sdmi_gemm_row_stats_slots": (C.c_int32, [C.POINTER(GemmArgs)]),
     "sdmi_row_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "sdmi_xattn_block": (C.c_int, [C.POINTER(XattnArgs), _vp]),
+    "sdmi_xattn_block_applies": (C.c_int, [C.POINTER(XattnArgs)]),
     "sdmi_gemm_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "sdmi_pack_tile_n": (_i32, [_i64, _i32]),
     "sdmi_pack_linear_k": (_i64, [_i64, _i32]),

@@ -593,6 +593,58 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
     return (out, out_stats) if row_stats else out
 
 
+XATTN_BLOCK = os.environ.get("SDMI_XATTN_BLOCK", "1") != "0"      # False: the three-launch form everywhere (A/B, tests)
+# One workgroup owns a 128-row panel for the whole chain and fills a CU alone (144 KiB of LDS), so the launch needs rows
+# for every CU before it beats three launches that tile finer.  UNet step, same process A/B (tools/ab_flag.py XATTN_BLOCK;
+# 5 such blocks a forward): 8192 rows + 0.014 ms, 16384 - 0.003, 32768 - 0.100, 65536 - 0.137.
+XATTN_MIN_ROWS = 16384
+
+
+def xattn_block_applies(x, pw_q, pw_o, k, v, nk, heads, rows_per_image, policy=True):
+    """Whether the cross-attention half of a transformer block runs as the one-launch sdmi_xattn_block: f16, C = 320
+    (5 heads of 64), plain (unfolded) to_q weight packed for the 160-column tile, a context of <= 128 keys, whole 128-row
+    panels per image - and (policy=True) enough rows for it to pay, the switch on."""
+    c = x.shape[-1]
+    m = x.numel() // c
+    if policy and not (XATTN_BLOCK and m >= XATTN_MIN_ROWS):
+        return False
+    return bool(x.dtype == F16 and c == 320 and heads == 5 and pw_q.dtype == F16 and pw_o.dtype == F16
+                and pw_q.ln_colsum is None and not pw_q.geglu and pw_q.n_out == 320 and pw_q.k == 320 and pw_q.tile_n == 160
+                and pw_o.n_out == 320 and pw_o.k == 320 and pw_o.tile_n == 160 and pw_o.out_dtype == F16
+                and pw_q.bias is None and nk <= 128 and m % 128 == 0 and rows_per_image % 128 == 0
+                and k.dtype == F16 and v.dtype == F16 and k.stride(-1) == 1 and v.stride(-1) == 1
+                and k.stride(0) % 8 == 0 and v.stride(0) % 8 == 0 and k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0)
+
+
+def xattn_block(x, ln, pw_q, pw_o, k, v, nk, heads, scale, rows_per_image, row_stats=False):
+    """out = to_out(softmax(scale * to_q(LayerNorm(x)) K^T) V) + bias + x in one launch (sdmi_xattn_block; conditions:
+    xattn_block_applies).  x: f16 [M, 320] token stream; k, v: f16 [images * nk, >= 320] (column slices allowed).
+    row_stats=True: -> (out, statistics of out) for a LayerNorm-folded consumer."""
+    _require(x, F16, "x")
+    m = x.numel() // 320
+    out = torch.empty_like(x)
+    a = hip.XattnArgs()
+    a.x, a.ldx, a.M, a.rows_per_image, a.C, a.heads = x.data_ptr(), 320, m, rows_per_image, 320, heads
+    gamma, beta = ln[0], ln[1]
+    _require(gamma, torch.float32, "ln gamma")
+    _require(beta, torch.float32, "ln beta")
+    a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), ln[2] if len(ln) > 2 else 1e-5
+    a.wq, a.wo = pw_q.w.data_ptr(), pw_o.w.data_ptr()
+    a.bias_o = pw_o.bias.data_ptr() if pw_o.bias is not None else None
+    a.k, a.v, a.ldk, a.ldv, a.nk = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), nk
+    a.scale = scale
+    a.out, a.ld_out = out.data_ptr(), 320
+    a.dtype = hip.DTYPE_F16
+    st_o = None
+    if row_stats:
+        st_o = torch.empty(m, 4, 2, dtype=torch.float32, device=x.device)
+        a.row_stats_out, a.row_stats_slots = st_o.data_ptr(), 4
+    # (one MFMA family for bench.py's table: the launch is counted with the linears - 2 of its 3 contractions are)
+    flops = 2 * m * 320 * 320 * 2 + 4 * m * nk * 320
+    _traced("linear", flops, (m, 320, 320, 0, 0), lambda: hip.check(hip.lib().sdmi_xattn_block(C.byref(a), _stream()), "sdmi_xattn_block"))
+    return (out, (st_o, 4) if row_stats else None) if row_stats else out
+
+
 def conv3x3(x, pw, stride=1, upsample=False, emb=None, res=None, out_nchw_f32=False, asym_pad=False, dup_rows=False):
     """3x3 conv, pad 1, on an NHWC bf16 image [B, H, W, Cin]; optional fused nearest-x2 input gather,
     time-embedding add (emb fp32 [B, Cout]) and residual add.  Returns NHWC 16-bit, or fp32 NCHW.

@@ -151,7 +151,9 @@ def pack_spatial_transformer(st, cd, kv_off=0):
             "qkv1": ops.pack_linear_cat([tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight], dtype=cd,
                                         ln=(tb.norm1.weight, tb.norm1.bias, tb.norm1.eps), keep_plain=c == 320),
             "o1": ops.pack_linear(tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias, dtype=cd, out_dtype=sd),
-            "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd, ln=(tb.norm2.weight, tb.norm2.bias, tb.norm2.eps)),
+            # (plain twin at 320 channels: ops.xattn_block normalises the token panel itself)
+            "q2": ops.pack_linear(tb.attn2.to_q.weight, dtype=cd, ln=(tb.norm2.weight, tb.norm2.bias, tb.norm2.eps),
+                                  keep_plain=c == 320),
             "o2": ops.pack_linear(tb.attn2.to_out[0].weight, tb.attn2.to_out[0].bias, dtype=cd, out_dtype=sd),
             "geglu": ops.pack_geglu(tb.feed_forward.net[0].proj.weight, tb.feed_forward.net[0].proj.bias, dtype=cd,
                                     ln=(tb.norm3.weight, tb.norm3.bias, tb.norm3.eps), keep_plain=True),
@@ -200,17 +202,28 @@ def run_spatial_transformer(e, h, kv, nk, pair_prefix=False):
         dup = pair_prefix and bi == 0
         # (dup: the output projection of the first self-attention stores every row twice - the duplication of the
         # guidance pairs where the context enters, without a copy kernel)
+        ko = be["kv_off"]
+        k2, v2 = kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci]
+        q2p = be["q2"].plain if be["q2"].plain is not None else be["q2"]
+        # the cross-attention half as one launch where ops.xattn_block is built for it (f16, 320 channels, <= 128 keys)
+        fused = t.dtype == torch.float16 and ops.xattn_block_applies(t if not dup else h_full.reshape(-1, c), q2p, be["o2"],
+                                                                     k2, v2, nk, heads, n)
         if dup and t.dtype not in ops.HALF_TYPES:       # fp32 mode (built for the 1e-5 gate, not for speed): a plain copy
             t, st = ops.linear(a, be["o1"], res=t), None
             t = torch.cat([t, t])
         else:
-            t, st = _linear_st(a, be["o1"], ops.fold_applies(be["q2"], b * n * (2 if dup else 1)), res=t, dup_rows=dup)
+            t, st = _linear_st(a, be["o1"], not fused and ops.fold_applies(be["q2"], b * n * (2 if dup else 1)), res=t,
+                               dup_rows=dup)
         if dup:
             h, b = h_full, 2 * b
-        q2 = ops.linear(t, be["q2"], ln=be["ln2"], stats=st)
-        ko = be["kv_off"]
-        a = ops.attention_d64(q2, kv[:, ko:ko + ci], kv[:, ko + ci:ko + 2 * ci], heads, b, n, nk, be["scale"])
-        t, st = _linear_st(a, be["o2"], ops.fold_applies(be["geglu"], b * n), res=t)
+        if fused:
+            want = ops.fold_applies(be["geglu"], b * n)
+            t = ops.xattn_block(t, be["ln2"], q2p, be["o2"], k2, v2, nk, heads, be["scale"], n, row_stats=want)
+            t, st = t if want else (t, None)
+        else:
+            q2 = ops.linear(t, be["q2"], ln=be["ln2"], stats=st)
+            a = ops.attention_d64(q2, k2, v2, heads, b, n, nk, be["scale"])
+            t, st = _linear_st(a, be["o2"], ops.fold_applies(be["geglu"], b * n), res=t)
         g = ops.linear(t, be["geglu"], ln=be["ln3"], stats=st)
         t, st = _linear_st(g, be["ff2"], bi + 1 < len(blocks) and ops.fold_applies(blocks[bi + 1]["qkv1"], b * n), res=t)
     out = ops.linear(t, e["pout"], res=h.reshape(b * n, c))

@@ -43,19 +43,21 @@ def test_abi_exports_every_declared_symbol(lib):
     assert lib.sdmi_groupnorm_workspace_bytes(2, 4096) > 0
 
 
-def test_gemm_args_struct_matches_header():
+@pytest.mark.parametrize("cname,pyname", [("sdmi_gemm_args", "GemmArgs"), ("sdmi_xattn_args", "XattnArgs")])
+def test_gemm_args_struct_matches_header(cname, pyname):
     from stablediffusion_amd import hip
-    fields = [f[0] for f in hip.GemmArgs._fields_]
-    prog = '#include "sdmi.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu", sizeof(sdmi_gemm_args));' + \
-        "".join(f'printf(" %zu", offsetof(sdmi_gemm_args, {f}));' for f in fields) + "return 0;}"
+    cls = getattr(hip, pyname)
+    fields = [f[0] for f in cls._fields_]
+    prog = f'#include "sdmi.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){{printf("%zu", sizeof({cname}));' + \
+        "".join(f'printf(" %zu", offsetof({cname}, {f}));' for f in fields) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
         open(src, "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    assert int(out[0]) == ctypes.sizeof(hip.GemmArgs)
+    assert int(out[0]) == ctypes.sizeof(cls)
     for f, off in zip(fields, out[1:]):
-        assert getattr(hip.GemmArgs, f).offset == int(off), f
+        assert getattr(cls, f).offset == int(off), f
 
 
 def test_argument_validation_without_gpu(lib):
@@ -70,6 +72,20 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sdmi_attention_d64(16, 16, 16, 16, 1, 1, 8, 8, 60, 64, 64, 64, 0.125, 0, None) == -2
     assert lib.sdmi_attention_d64(16, 16, 16, 16, 1, 1, 8, 8, 64, 64, 64, 64, 0.125, 7, None) == -1     # unknown dtype
     assert lib.sdmi_groupnorm(16, None, 30, 0, 16, 16, 16, 1, 8, 1e-5, 1, 0, 16, 1 << 20, None) == -2
+    xa = hip.XattnArgs()
+    assert lib.sdmi_xattn_block(ctypes.byref(xa), None) == -1 and lib.sdmi_xattn_block_applies(ctypes.byref(xa)) == 0
+    xa.x = xa.out = xa.wq = xa.wo = xa.k = xa.v = 256
+    xa.ln_gamma = xa.ln_beta = 256
+    xa.ldx = xa.ld_out = 320
+    xa.ldk = xa.ldv = 640
+    xa.M, xa.rows_per_image, xa.C, xa.heads, xa.nk, xa.dtype, xa.ln_eps = 256, 128, 320, 5, 77, hip.DTYPE_F16, 1e-5
+    assert lib.sdmi_xattn_block_applies(ctypes.byref(xa)) == 1
+    for field, bad in (("nk", 129), ("M", 192), ("rows_per_image", 96), ("C", 640), ("dtype", hip.DTYPE_BF16), ("ldk", 324)):
+        keep = getattr(xa, field)
+        setattr(xa, field, bad)
+        assert lib.sdmi_xattn_block_applies(ctypes.byref(xa)) == 0, field
+        assert lib.sdmi_xattn_block(ctypes.byref(xa), None) == -1, field       # refused before any launch
+        setattr(xa, field, keep)
 
 
 def test_factory_surface():

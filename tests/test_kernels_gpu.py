@@ -807,6 +807,47 @@ def test_row_statistics_travel_with_the_token_stream(dev, m, k, n, res, dup):
         ops.linear(t[:-1], cons, ln=ln, stats=(st, slots))          # statistics of other rows
 
 
+@pytest.mark.parametrize("nb,n,nk", [(2, 1024, 77), (1, 128, 64), (3, 256, 128), (2, 384, 100), (16, 4096, 77)])
+def test_cross_attention_block_as_one_launch(dev, nb, n, nk):
+    """sdmi_xattn_block: norm2 -> attn2.to_q -> attention over the prompt's keys -> attn2.to_out + residual
+    (attention.py:518-528, 300-380) for C = 320 in one kernel, against the three-launch chain of the same ops and
+    against torch in fp32 on the f16-rounded operands; with the row statistics a LayerNorm-folded consumer takes."""
+    ops = _ops()
+    c, heads = 320, 5
+    x = (rnd((nb * n, c), dev, 81) * 1.3 + 0.2).to(F16)
+    gamma, beta = 1.0 + 0.2 * rnd((c,), dev, 82), 0.2 * rnd((c,), dev, 83)
+    ln = (gamma, beta, 1e-5)
+    wq, wo, bo = rnd((c, c), dev, 84, 0.06), rnd((c, c), dev, 85, 0.06), rnd((c,), dev, 86)
+    kv = rnd((nb * nk, 1000), dev, 87).to(F16)          # K | V as column slices of a wider matrix, as the UNet keeps them
+    k, v = kv[:, 40:40 + c], kv[:, 400:400 + c]
+    pq, po = ops.pack_linear(wq, dtype=F16), ops.pack_linear(wo, bo, dtype=F16)
+    scale = 64 ** -0.5
+    assert ops.xattn_block_applies(x, pq, po, k, v, nk, heads, n, policy=False)
+    assert ops.xattn_block_applies(x, pq, po, k, v, nk, heads, n) == (ops.XATTN_BLOCK and nb * n >= ops.XATTN_MIN_ROWS)
+    out, (st, slots) = ops.xattn_block(x, ln, pq, po, k, v, nk, heads, scale, n, row_stats=True)
+    out2 = ops.xattn_block(x, ln, pq, po, k, v, nk, heads, scale, n)
+    assert torch.equal(out, out2)
+    # the three-launch chain
+    qq = ops.linear(x, pq, ln=ln)
+    aa = ops.attention_d64(qq, k, v, heads, nb, n, nk, scale)
+    chain = ops.linear(aa, po, res=x)
+    # torch, fp32 on rounded operands
+    xf = x.float()
+    qf = F.linear(F.layer_norm(xf, (c,), gamma, beta, 1e-5), wq.to(F16).float())
+    qh = qf.reshape(nb, n, heads, 64).permute(0, 2, 1, 3)
+    kh = k.float().reshape(nb, nk, heads, 64).permute(0, 2, 1, 3)
+    vh = v.float().reshape(nb, nk, heads, 64).permute(0, 2, 1, 3)
+    ah = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh
+    ref = F.linear(ah.permute(0, 2, 1, 3).reshape(nb * n, c), wo.to(F16).float(), bo) + xf
+    assert rel_err(out, ref) < 1.5e-3 and rel_err(chain, ref) < 1.5e-3
+    assert rel_err(out, chain.float()) < 1.2e-3
+    tot, of = st.double().sum(1), out.double()
+    assert slots == 4 and (tot[:, 0] - of.sum(1)).abs().max() < 2e-3 * of.abs().sum(1).max()
+    assert (tot[:, 1] - (of * of).sum(1)).abs().max() < 2e-3 * (of * of).sum(1).max()
+    assert not ops.xattn_block_applies(x[:-1], pq, po, k, v, nk, heads, n, policy=False)          # ragged panel
+    assert not ops.xattn_block_applies(x, pq, po, k, v, 129, heads, n, policy=False)              # too many keys
+
+
 def test_layernorm_fold_is_f16_only_and_checked(dev):
     ops = _ops()
     gamma, beta = 1.0 + 0.2 * rnd((320,), dev, 63), 0.3 * rnd((320,), dev, 64)
