@@ -807,7 +807,9 @@ def test_row_statistics_travel_with_the_token_stream(dev, m, k, n, res, dup):
         ops.linear(t[:-1], cons, ln=ln, stats=(st, slots))          # statistics of other rows
 
 
-@pytest.mark.parametrize("nb,n,nk", [(2, 1024, 77), (1, 128, 64), (3, 256, 128), (2, 384, 100), (16, 4096, 77)])
+@pytest.mark.parametrize("nb,n,nk", [(2, 1024, 77), (1, 128, 64), (3, 256, 128), (2, 384, 100), (16, 4096, 77),
+                                      (2, 128, 1), (5, 128, 31), (2, 256, 32), (2, 256, 33), (1, 512, 65), (2, 128, 96),
+                                      (3, 128, 97)])
 def test_cross_attention_block_as_one_launch(dev, nb, n, nk):
     """sdmi_xattn_block: norm2 -> attn2.to_q -> attention over the prompt's keys -> attn2.to_out + residual
     (attention.py:518-528, 300-380) for C = 320 in one kernel, against the three-launch chain of the same ops and
