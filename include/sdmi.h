@@ -183,6 +183,7 @@ int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);
  * the chain on 128 rows resident in LDS.  x, out: f16 [M, ld]; wq, wo: f16 [320][320] as sdmi_pack_linear packs them with
  * tile_n = 160 (PLAIN weights: the LayerNorm is computed on the resident rows, exact two-pass statistics); k, v: f16
  * [images * nk, ld] (image b's keys at rows b * nk ...), head h at columns h * 64; rows_per_image = tokens of one image.
+ * bias_o may be NULL (no output bias); out may be x itself (in place: a workgroup reads its 128 rows before it writes them).
  * row_stats_out (optional, row_stats_slots = 4): as sdmi_gemm_args.row_stats_out, for a LayerNorm-folded consumer of `out`.
  * sdmi_xattn_block_applies() == 1 iff the problem fits: dtype SDMI_DTYPE_F16, C == 320, heads == 5, nk <= 128, M and
  * rows_per_image multiples of 128, 16-byte aligned pointers, leading dimensions % 8 == 0. */

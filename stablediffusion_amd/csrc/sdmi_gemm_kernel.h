@@ -384,7 +384,7 @@ __device__ __forceinline__ void epilogue_rows16(const sdmi_gemm_args& p, f32x4 (
 }
 
 // The loads of epilogue_rows16<..., PRE = true>: column bias and residual of the wave's tile, in the epilogue's own lane ->
-// element map (p.bias and p.res must be set).
+// element map (p.res must be set; a null p.bias reads as zeros).
 template <int DT, int TN, int MI, int P0>
 __device__ __forceinline__ void epilogue_rows16_prefetch(const sdmi_gemm_args& p, int64_t mrow, int64_t ncol_w, int fq,
                                                          int64_t zoff_res, f32x4 (&bq)[TN], uint2 (&rq_all)[MI][TN]) {
@@ -397,7 +397,7 @@ __device__ __forceinline__ void epilogue_rows16_prefetch(const sdmi_gemm_args& p
         const int64_t n = ncol0 + ni * 16;
         nval[ni] = n < p.N;
         bq[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.bias != nullptr && nval[ni]) bq[ni] = *reinterpret_cast<const f32x4*>(p.bias + n);
     }
     const unsigned short* const resp = reinterpret_cast<const unsigned short*>(p.res) + zoff_res;
 #pragma unroll

@@ -850,6 +850,43 @@ def test_cross_attention_block_as_one_launch(dev, nb, n, nk):
     assert not ops.xattn_block_applies(x, pq, po, k, v, 129, heads, n, policy=False)              # too many keys
 
 
+def test_cross_attention_block_strided_operands_through_the_c_abi(dev):
+    """sdmi_xattn_block called as a binding would call it: x / out as column slices of wider matrices (ldx, ld_out != 320),
+    no output bias, and out == x (in place: each lane reads exactly the elements it later writes)."""
+    import ctypes
+    from stablediffusion_amd import hip
+    ops = _ops()
+    nb, n, nk, c = 2, 256, 77, 320
+    xw = (rnd((nb * n, 512), dev, 91) * 0.9).to(F16)
+    x = xw[:, 64:64 + c]
+    ow = torch.zeros(nb * n, 448, dtype=F16, device=dev)
+    gamma, beta = 1.0 + 0.1 * rnd((c,), dev, 92), 0.1 * rnd((c,), dev, 93)
+    wq, wo = rnd((c, c), dev, 94, 0.06), rnd((c, c), dev, 95, 0.06)
+    kv = rnd((nb * nk, 2 * c), dev, 96).to(F16)
+    k, v = kv[:, :c], kv[:, c:]
+    pq, po = ops.pack_linear(wq, dtype=F16), ops.pack_linear(wo, dtype=F16)
+    ref = ops.xattn_block(x.contiguous(), (gamma, beta, 1e-5), pq, po, k, v, nk, 5, 0.125, n)
+
+    def call(xt, ot):
+        a = hip.XattnArgs()
+        a.x, a.ldx, a.M, a.rows_per_image, a.C, a.heads = xt.data_ptr(), xt.stride(0), nb * n, n, c, 5
+        a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), 1e-5
+        a.wq, a.wo, a.bias_o = pq.w.data_ptr(), po.w.data_ptr(), None
+        a.k, a.v, a.ldk, a.ldv, a.nk, a.scale = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), nk, 0.125
+        a.out, a.ld_out, a.dtype = ot.data_ptr(), ot.stride(0), hip.DTYPE_F16
+        assert hip.lib().sdmi_xattn_block_applies(ctypes.byref(a)) == 1
+        hip.check(hip.lib().sdmi_xattn_block(ctypes.byref(a), torch.cuda.current_stream().cuda_stream), "sdmi_xattn_block")
+        torch.cuda.synchronize()
+
+    call(x, ow[:, 32:32 + c])
+    assert torch.equal(ow[:, 32:32 + c], ref)
+    assert not bool(ow[:, :32].any()) and not bool(ow[:, 32 + c:].any())          # nothing outside the slice
+    xin = xw.clone()
+    call(xin[:, 64:64 + c], xin[:, 64:64 + c])                                      # in place
+    assert torch.equal(xin[:, 64:64 + c], ref)
+    assert torch.equal(xin[:, :64], xw[:, :64]) and torch.equal(xin[:, 64 + c:], xw[:, 64 + c:])
+
+
 def test_layernorm_fold_is_f16_only_and_checked(dev):
     ops = _ops()
     gamma, beta = 1.0 + 0.2 * rnd((320,), dev, 63), 0.3 * rnd((320,), dev, 64)
