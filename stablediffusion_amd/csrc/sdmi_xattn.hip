@@ -461,7 +461,7 @@ extern "C" int sdmi_xattn_block_applies(const sdmi_xattn_args* a) {
     if (a->nk <= 0 || a->nk > 128) return 0;
     if (a->ldx % 8 || a->ld_out % 8 || a->ldk % 8 || a->ldv % 8 || a->ldk < 320 || a->ldv < 320 || a->ldx < 320 || a->ld_out < 320) return 0;
     if ((((uintptr_t)a->x | (uintptr_t)a->out | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->wq | (uintptr_t)a->wo) & 15) != 0) return 0;
-    if ((a->M / XBM) > 0x7fffffffLL) return 0;
+    if ((a->M / XBM) > 0x7fffffffLL || a->ldx > (1 << 22)) return 0;      // (panel row offsets are 32-bit byte offsets)
     return 1;
 }
 
