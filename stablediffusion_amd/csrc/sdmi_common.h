@@ -198,6 +198,22 @@ __device__ __forceinline__ f32x4 gelu_erf_f4(const f32x4& g) {
 #define SDMI_LD_S(N) "s_add_u32 m0, %[d0], %[o" #N "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #N "], %[sb]\n\t"
 #define SDMI_LD_V(N) "s_add_u32 m0, %[d0], %[o" #N "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #N "], off\n\t"
 
+template <int O0>
+__device__ __forceinline__ void glds_s1(unsigned d0, const void* sb, unsigned v0) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_S(0) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [sb] "s"(sb), [v0] "v"(v0), [o0] "n"(O0)
+                 : "memory", "scc");
+}
+template <int O0>
+__device__ __forceinline__ void glds_v1(unsigned d0, const void* v0) {
+    unsigned keep;
+    asm volatile(SDMI_M0_SAVE SDMI_LD_V(0) SDMI_M0_REST
+                 : [keep] "=&s"(keep)
+                 : [d0] "s"(d0), [v0] "v"(v0), [o0] "n"(O0)
+                 : "memory", "scc");
+}
 template <int O0, int STEP = 8192>
 __device__ __forceinline__ void glds_s2(unsigned d0, const void* sb, unsigned v0, unsigned v1) {
     unsigned keep;

@@ -151,6 +151,12 @@ SDMI_GEMM_UNIT_DECL(m0_bf16) SDMI_GEMM_UNIT_DECL(m0_f16) SDMI_GEMM_UNIT_DECL(m1_
 int sdmi_gemm_unit_attrs_m0_f16_lnf();                                   // sdmi_gemm_lnf.hip (LayerNorm folded, mode 0, f16)
 void sdmi_gemm_unit_launch_m0_f16_lnf(int wide, int variant, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_wide_attrs_f16_lnf();
+int sdmi_gemm_small_attrs_m0_bf16();                                     // the 64-column tile (mode 0): sdmi_gemm_m0_*.hip, sdmi_gemm_lnf.hip
+int sdmi_gemm_small_attrs_m0_f16();
+int sdmi_gemm_small_attrs_m0_f16_lnf();
+void sdmi_gemm_small_launch_m0_bf16(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_small_launch_m0_f16(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_small_launch_m0_f16_lnf(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 void sdmi_gemm_wide_launch_f16_lnf(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_wide_attrs_bf16();                                         // sdmi_gemm_wide_*.hip
 int sdmi_gemm_wide_attrs_f16();
@@ -161,6 +167,8 @@ int sdmi_conv_narrow_launch(const sdmi_gemm_args& p, hipStream_t s);     // sdmi
 
 // Row tile the launcher picks: 256 rows once that still gives every CU a block, else 128 rows.
 static int pick_tile_m(int64_t M, int64_t N_w, int tile_n, int64_t problems) {
+    if (tile_n == 64)       // the small tile: 128 rows once that gives every CU a block, else 64
+        return ((M + 127) / 128) * ((N_w + 63) / 64) * problems >= 256 ? 128 : 64;
     const int bn = tile_n == 160 ? 160 : 128;
     const int64_t tiles = ((M + 255) / 256) * ((N_w + bn - 1) / bn) * problems;
     return tiles >= 256 ? 256 : 128;
@@ -260,9 +268,14 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     p.split_k = split;
     const int64_t n_w = p.geglu ? 2 * p.N : p.N;
     const int BN = p.tile_n == 0 ? 128 : p.tile_n;
-    if (BN != 128 && BN != 160 && BN != 256) return SDMI_ERR_BAD_ARG;
+    if (BN != 64 && BN != 128 && BN != 160 && BN != 256) return SDMI_ERR_BAD_ARG;
     if (BN == 160 && p.geglu) return SDMI_ERR_BAD_ARG;      // GEGLU pairs 16-column blocks inside a wave
-    if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
+    if (BN == 64) {
+        // the small tile: mode 0, 64 columns x 128 | 64 rows, three stages; no GEGLU (a wave holds two 16-column blocks),
+        // no LayerNorm on resident rows (the panel kernel's)
+        if (p.mode != 0 || p.geglu || p.ln_gamma != nullptr || p.algo == 2 || p.stages == 2) return SDMI_ERR_BAD_ARG;
+        if (p.tile_m != 0 && p.tile_m != 64 && p.tile_m != 128) return SDMI_ERR_BAD_ARG;
+    } else if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
     if (p.stages != 0 && p.stages != 2 && p.stages != 3) return SDMI_ERR_BAD_ARG;
     if (BN == 256 && !wide_applies(p)) return SDMI_ERR_BAD_ARG;
     const int BM = BN == 256 ? 256 : p.tile_m != 0 ? p.tile_m : pick_tile_m(p.M, n_w, BN, batch);
@@ -296,7 +309,7 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         if (p.dtype != SDMI_DTYPE_F16 || p.mode != 0 || p.A2 != nullptr || batch > 1 || (n_w & 3) != 0 || p.stages == 2 ||
             p.algo == 2 || p.ln_gamma != nullptr || p.ln_beta != nullptr || p.emb != nullptr || p.bias_per_row)
             return SDMI_ERR_BAD_ARG;
-        if (p.ln_colsum != nullptr && (p.ln_stats == nullptr || p.ln_stats_slots < 1 || p.ln_stats_slots > 32 ||
+        if (p.ln_colsum != nullptr && (p.ln_stats == nullptr || p.ln_stats_slots < 1 || p.ln_stats_slots > 48 ||
                                        ((p.ln_stats_slots & 1) && p.ln_stats_slots > 4) || (((uintptr_t)p.ln_stats) & 15) != 0 || !(p.ln_eps >= 0.f)))
             return SDMI_ERR_BAD_ARG;
         if (p.ln_colsum == nullptr && p.ln_stats != nullptr) return SDMI_ERR_BAD_ARG;
@@ -304,7 +317,8 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         if (p.row_stats_out != nullptr) {
             // written by the fast 16-bit epilogue (or the row-wise reduce pass): its conditions, as for dup_rows
             if (p.geglu || p.out_kind != 0 || (p.N & 7) != 0 || p.N <= 16 || ((p.ld_out | p.ld_res) & 7) != 0 || p.res_f32 ||
-                (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0 || p.row_stats_slots != row_stats_slots(p))
+                (((uintptr_t)p.out | (uintptr_t)p.res) & 15) != 0 || p.row_stats_slots != row_stats_slots(p) ||
+                p.row_stats_slots > 48)      // (what a LayerNorm-folded consumer can read)
                 return SDMI_ERR_BAD_ARG;
         }
     }
@@ -338,6 +352,8 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         bool ok = true;
         for (int i = 0; i < 4; ++i) ok = (fns[i]() == SDMI_OK) && ok;
         ok = (sdmi_gemm_unit_attrs_m0_f16_lnf() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16_lnf() == SDMI_OK) && ok;
+        ok = (sdmi_gemm_small_attrs_m0_bf16() == SDMI_OK) && (sdmi_gemm_small_attrs_m0_f16() == SDMI_OK) &&
+             (sdmi_gemm_small_attrs_m0_f16_lnf() == SDMI_OK) && ok;
         return (sdmi_gemm_wide_attrs_bf16() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16() == SDMI_OK) && ok;
     });
     if (attr_status != SDMI_OK) return attr_status;
@@ -345,7 +361,10 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) {
+    if (BN == 64) {
+        if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) sdmi_gemm_small_launch_m0_f16_lnf(BM == 64, grid, s, p);
+        else (f16 ? sdmi_gemm_small_launch_m0_f16 : sdmi_gemm_small_launch_m0_bf16)(BM == 64, grid, s, p);
+    } else if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) {
         if (BN == 256) sdmi_gemm_wide_launch_f16_lnf(0, grid, s, p);
         else           sdmi_gemm_unit_launch_m0_f16_lnf(wide, tall ? 1 : 0, grid, s, p);
     }

@@ -21,6 +21,9 @@ __device__ const uint4 sdmi_zeros[ZERO_ELEMS / 8 + 1] = {};
 // Block tile BM x BN x BK with BN = 32*TN: TN = 4 (128 columns) or TN = 5 (160 columns; every UNet width is a
 // multiple of 160, so those layers lose nothing to column padding).
 // and BM = 64*MI: MI = 4 (256 rows) or MI = 2 (128 rows); 8 waves, 3-stage ring, one block per CU.
+// The small tile (round 3; mode 0): TN = 2 (64 columns) with MI = 2 | 1 (128 | 64 rows) - for launches of a few hundred rows
+// (the UNet at batch 1 - 2), where the larger tiles leave most of the chip without a block: 48 - 72 KiB of LDS, so two or
+// three of its blocks also share a CU.
 constexpr int BK = 64;
 constexpr int lds_bytes(int tn, int mi, int nst) { return nst * (mi * 64 + tn * 32) * (BK / 8) * 16; }
 constexpr int GROUP_M = 8;
@@ -168,7 +171,7 @@ __device__ __forceinline__ void lnf_rows_mean_rstd(const sdmi_gemm_args& p, int6
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) s1[mi] = s2[mi] = 0.f;
 #pragma unroll
-    for (int batch = 0; batch < 2; ++batch) {
+    for (int batch = 0; batch < 3; ++batch) {
         if (batch * 8 >= units) break;                  // (uniform)
         f32x4 raw[2][MI];
 #pragma unroll
@@ -212,8 +215,16 @@ __device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[
     for (int ni = 0; ni < TN; ++ni) {
         const int64_t wcol = wcol0 + ni * 16;
         const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + wcol);      // (padded to the column tile: sdmi.h)
+        // (Element by element on purpose.  Written as one f32x4 expression, hipcc (ROCm 7.2) put the row's mean on the SECOND
+        // source of two of the packed fmas - v_pk_fma_f32 d, cs, mean, d op_sel:[0,1,0] - and on this part that form dropped
+        // the product from the LOW result in lanes 48-63 now and then, whenever two of these workgroups shared a CU (the
+        // 128 x 64 tile past 256 blocks: a handful of outputs per launch came out as if the mean were zero; 28 of 30
+        // launches; never with the mean broadcast from the first source, which is what this form compiles to.
+        // tests/test_host_cpu.py::test_no_packed_fma_with_a_broadcast_second_source keeps the form out of the library.)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (acc[ni][mi] - mean[mi] * cs) * rstd[mi];
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ni][mi][j] = __builtin_fmaf(-mean[mi], cs[j], acc[ni][mi][j]) * rstd[mi];
     }
 }
 
@@ -473,8 +484,11 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     constexpr int W_CHUNKS = BN * (BK / 8);     // 16-byte chunks per W tile
     constexpr int STAGE_CHUNKS = A_CHUNKS + W_CHUNKS;
     constexpr int RPI = 64;                     // tile rows one DMA instruction of the whole block covers
-    constexpr int NA = BM / RPI;                // A instructions per thread and stage (4 | 2)
-    constexpr int NW = BN / RPI;                // W instructions every thread issues (2)
+    constexpr int NA = BM / RPI;                // A instructions per thread and stage (4 | 2 | 1)
+    constexpr int NW = BN / RPI;                // W instructions every thread issues (2 | 1)
+    static_assert(NA == 4 || NA == 2 || NA == 1, "row tile");
+    static_assert(NW == 2 || NW == 1, "column tile");
+    static_assert(MODE == 0 || (NA >= 2 && NW == 2), "the small tile is built for mode 0 only");
     constexpr bool W_TAIL = (BN % RPI) != 0;    // leftover 32 W rows (TN = 5): waves 0..3 issue one more
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint4* const lds = reinterpret_cast<const uint4*>(smem);
@@ -609,15 +623,17 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     do {                                                                                                   \
         const unsigned d0_ = d_wave + (BUF) * (STAGE_CHUNKS * 16);                                         \
         const int64_t k0_ = (int64_t)(KT) * BK;                                                            \
-        if (MODE == 0) {                                                                                   \
+        if constexpr (MODE == 0) {                                                                         \
             if (k0_ + BK <= k_valid) {                                                                     \
                 const bool second_ = (A2 != nullptr) && (k0_ >= p.k_split);                                \
                 const unsigned short* sa_ = second_ ? A2 + m0 * p.lda2 + (k0_ - p.k_split) : A + m0 * p.lda + k0_; \
-                if (NA == 4)                                                                               \
+                if constexpr (NA == 4)                                                                     \
                     glds_s4<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[1] : a_voff[1], \
                                second_ ? a2_voff[NA - 2] : a_voff[NA - 2], second_ ? a2_voff[NA - 1] : a_voff[NA - 1]); \
+                else if constexpr (NA == 2)                                                                \
+                    glds_s2<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[NA - 1] : a_voff[NA - 1]); \
                 else                                                                                       \
-                    glds_s2<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0], second_ ? a2_voff[1] : a_voff[1]); \
+                    glds_s1<0>(d0_, sa_, second_ ? a2_voff[0] : a_voff[0]);                                \
             } else {                                                                                       \
                 const int64_t k_ = k0_ + lc * 8;                                                           \
                 const bool kin_ = k_ < k_valid;      /* columns past k_valid (K padding) read as zero */   \
@@ -625,8 +641,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 const unsigned short* base_ = second_ ? A2 : A;                                            \
                 const int64_t ld_ = second_ ? p.lda2 : p.lda;                                              \
                 const int64_t kk_ = second_ ? k_ - p.k_split : k_;                                         \
-                SDMI_STAGE_A0(0, kk_, base_, ld_, d0_); SDMI_STAGE_A0(1, kk_, base_, ld_, d0_);            \
-                if (NA == 4) { SDMI_STAGE_A0(NA - 2, kk_, base_, ld_, d0_); SDMI_STAGE_A0(NA - 1, kk_, base_, ld_, d0_); } \
+                SDMI_STAGE_A0(0, kk_, base_, ld_, d0_);                                                    \
+                if constexpr (NA >= 2) SDMI_STAGE_A0(1, kk_, base_, ld_, d0_);                             \
+                if constexpr (NA == 4) { SDMI_STAGE_A0(NA - 2, kk_, base_, ld_, d0_); SDMI_STAGE_A0(NA - 1, kk_, base_, ld_, d0_); } \
             }                                                                                              \
         } else if (conv_fast) {                                                                            \
             if (f_new_tap) {                                                                               \
@@ -649,8 +666,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
             c_ci += BK;                                                                                    \
             while (c_ci >= p.Cin) { c_ci -= p.Cin; ++c_tap; }                                              \
         }                                                                                                  \
-        if (w_tail_wave) glds_s3<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1], w_voff[2]);       \
-        else             glds_s2<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1]);                  \
+        if constexpr (NW == 1) glds_s1<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0]);                       \
+        else if (w_tail_wave)  glds_s3<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1], w_voff[2]); \
+        else                   glds_s2<A_CHUNKS * 16>(d0_, w_tile + k0_, w_voff[0], w_voff[1]);            \
     } while (0)
 #define SDMI_WAIT_DMA(KEEP)                                                                                \
     do {                                                                                                   \
@@ -976,4 +994,22 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     void sdmi_gemm_unit_launch_##NAME(int wide, int variant, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {   \
         hipLaunchKernelGGL(lnf_kernels[wide][variant], grid, dim3(512),                                             \
                            lds_bytes(wide ? 5 : 4, variant == 1 ? 4 : 2, 3), s, p);                                 \
+    }
+
+// The small tile (64 columns; 128 | 64 rows; three stages; mode 0): [0] = 128 rows, [1] = 64 rows.
+#define SDMI_GEMM_UNIT_SMALL(DT, LNF, NAME)                                                                         \
+    namespace {                                                                                                     \
+    typedef void (*small_kern_t_##NAME)(const sdmi_gemm_args);                                                      \
+    const small_kern_t_##NAME small_kernels_##NAME[2] = {sdmi_gemm_kernel<0, DT, 2, 2, 3, LNF>,                     \
+                                                         sdmi_gemm_kernel<0, DT, 2, 1, 3, LNF>};                    \
+    }                                                                                                               \
+    int sdmi_gemm_small_attrs_##NAME() {                                                                            \
+        for (int d = 0; d < 2; ++d)                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_kernels_##NAME[d]),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, d ? 1 : 2, 3)) != hipSuccess) \
+                return SDMI_ERR_LAUNCH;                                                                             \
+        return SDMI_OK;                                                                                             \
+    }                                                                                                               \
+    void sdmi_gemm_small_launch_##NAME(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {             \
+        hipLaunchKernelGGL(small_kernels_##NAME[rows64 ? 1 : 0], grid, dim3(512), lds_bytes(2, rows64 ? 1 : 2, 3), s, p); \
     }

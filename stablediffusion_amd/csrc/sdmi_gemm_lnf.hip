@@ -3,3 +3,4 @@
 #include "sdmi_gemm_wide.h"
 SDMI_GEMM_UNIT_LNF(m0_f16_lnf)
 SDMI_GEMM_WIDE_UNIT_LNF(f16_lnf)
+SDMI_GEMM_UNIT_SMALL(1, true, m0_f16_lnf)

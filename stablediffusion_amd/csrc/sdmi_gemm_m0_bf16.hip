@@ -1,3 +1,4 @@
 // sdmi_gemm instantiation unit: mode 0 (linear / conv1x1), bf16 operands.
 #include "sdmi_gemm_kernel.h"
 SDMI_GEMM_UNIT(0, 0, m0_bf16)
+SDMI_GEMM_UNIT_SMALL(0, false, m0_bf16)

@@ -301,6 +301,8 @@ def pack_conv3x3(weight, bias=None, dtype=BF16, tile_n=None, out_dtype=None):
 FORCE_ALGO = 0        # development aid / tests: sdmi_gemm_args.algo (0 auto, 1 tiled kernel, 2 panel kernel)
 FORCE_TILE_M = 0      # development aid (tools/bench_gemm.py): 0 = the library picks the row tile, else 128 | 256
 FORCE_WIDE = 0        # development aid: 1 = the 256 x 256 x 32 tile wherever it applies
+FORCE_TILE_N = 0      # development aid (tools/bench_gemm.py): 64 = the small tile (64 columns, FORCE_TILE_M = 64 | 128 rows) where it applies
+SMALL_TILE = os.environ.get("SDMI_SMALL_TILE", "1") != "0"      # False: _plan_gemm never picks the 64-column tile (A/B, tests)
 WIDE_TILE = True      # False: _plan_gemm never picks the 256 x 256 x 32 tile (A/B, tests)
 
 _CUS = 256            # MI355X compute units; the GEMM kernel runs one 8-wave block per CU at a time
@@ -324,7 +326,7 @@ def _wide_wins(m, n_w, nk, tile_n):
 
 
 @functools.lru_cache(maxsize=None)
-def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False):
+def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False, small_ok=False):
     """(tile_m, split_k, stages, tile_n) from a small occupancy model, in microseconds.  A launch of B blocks puts
     ceil(B/256) blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed
     prologue/epilogue; splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to
@@ -358,6 +360,19 @@ def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False):
                 cost += (2 * s + 0.5) * m * n_w * 4 / 12.0e6 + 6.0   # slab write+read (mostly L2/MALL) + the extra launch
             if best_cost is None or cost < best_cost * 0.97:
                 best, best_cost = (tile_m, s, 3, tile_n), cost
+    if small_ok:
+        # The 64-column tile (round 3): 64 x 64 or 128 x 64 blocks for launches whose larger tiles leave most CUs without a
+        # block (a few hundred rows: the UNet at batch 1 - 2, the 8 x 8 level at any batch).  Unsplit only - every split
+        # measured slower than the unsplit small tile (tools/small_tile_check.py, hipGraph replay, in the units of the
+        # costs above = measured - 4.8 us of launch): 64 x 64 costs 0.30 us a k-tile, 128 x 64 0.39, with a far shorter
+        # prologue / epilogue than the 160-column tiles; beyond one block per CU the co-resident blocks (three / two per
+        # CU) share the CU's fill rate.  512 x 1280 x 1280 18.0 -> 9.7 us, 2048 x 640 x 640 12.7 -> 8.3, 128 x 1280 x 1280
+        # 14.4 -> 9.4, 2048 x 640 x 2560 25.0 (split 4) -> 20.4.
+        for tile_m, step_us, fixed in ((64, 0.30, -1.0), (128, 0.39, -0.9)):
+            rounds = math.ceil(math.ceil(m / tile_m) * math.ceil(n_w / 64) / _CUS)
+            cost = max(step_us * nk + fixed, 0.5) + (rounds - 1) * (step_us * nk + 1.5)
+            if cost < best_cost * 0.95:
+                best, best_cost = (tile_m, 1, 3, 64), cost
     return best
 
 
@@ -415,7 +430,7 @@ def _narrow_conv_applies(a, pw):
                 and a.H == a.Ho and a.W_in == a.Wo)
 
 
-def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m):
+def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, alpha, m, allow_small=True):
     a.W = pw.w.data_ptr()
     a.dtype = _dt(pw.dtype)
     a.bias = pw.bias.data_ptr() if (bias_on and pw.bias is not None) else None
@@ -460,14 +475,20 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
     if wide_ok:
         a.tile_n, a.split_k = 256, 1
         wide_ok = bool(hip.lib().sdmi_gemm_wide_applies(C.byref(a)))
-    a.tile_m, sk, a.stages, a.tile_n = _plan_gemm(m, n_w, pw.k, pw.tile_n, wide_ok, bool(pw.geglu))
+    # the 64-column tile (mode 0, no GEGLU): the packed weight must hold whole 64-row tiles
+    small_ok = bool(allow_small and a.mode == 0 and not pw.geglu and not FORCE_ALGO and pw.w.shape[0] >= _round_up(n_w, 64))
+    a.tile_m, sk, a.stages, a.tile_n = _plan_gemm(m, n_w, pw.k, pw.tile_n, wide_ok, bool(pw.geglu),
+                                                  small_ok and SMALL_TILE and not FORCE_TILE_M)
     if FORCE_WIDE and wide_ok:
         a.tile_m, sk, a.tile_n = 256, 1, 256
-    if _auto_split_k is not _AUTO_SPLIT_K or a.tile_n != 256:
+    if _auto_split_k is not _AUTO_SPLIT_K or a.tile_n not in (256, 64):
         sk = _auto_split_k(m, n_w, pw.k, pw.tile_n)      # (separate hook: tests and tools pin it)
     if FORCE_TILE_M:
         a.tile_m = FORCE_TILE_M & ~1
         a.stages = 2 if FORCE_TILE_M & 1 else 3         # 129 = 128 rows, two stages
+    if FORCE_TILE_N == 64 and small_ok:
+        a.tile_n, a.stages = 64, 3
+        a.tile_m = FORCE_TILE_M if FORCE_TILE_M in (64, 128) else 0
     if a.dup_rows:
         sk = 1                  # the duplicated store lives in the fast 16-bit epilogue, not in the split-K reduce pass
     if _narrow_conv_applies(a, pw):
@@ -565,7 +586,9 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
             out = torch.empty(2 * m, pw.n_out, dtype=out_dtype, device=x.device)
         else:
             out = torch.empty(*x.shape[:-1], pw.n_out, dtype=out_dtype, device=x.device)
-        keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m)
+        # (row statistics on the 64-column tile: one slot per 32 columns, and a consumer reads at most 48)
+        keep = _fill_common(a, pw, out, bias, emb, rows_per_batch, res, act, 0 if out_dtype in HALF_TYPES else 1, alpha, m,
+                            allow_small=not (row_stats and _round_up(pw.n_out, 64) // 32 > 48))
     out_stats = None
     if row_stats and pw.dtype == F16 and not pw.split_cp and out_nchw_f32 is None and out_dtype == F16 and not pw.geglu \
             and x2 is None and emb is None:
@@ -583,7 +606,7 @@ def linear(x, pw, x2=None, emb=None, rows_per_batch=None, res=None, act=0, out_d
         if hip.lib().sdmi_gemm_panel_applies(C.byref(a)):
             a.ln_gamma, a.ln_beta, a.ln_eps = gamma.data_ptr(), beta.data_ptr(), ln[2] if len(ln) > 2 else 1e-5
             a.a_f16 = 1 if stream_in else 0
-            if a.tile_n == 256:       # the plan's 256 x 256 x 32 tile gives way to the kernel that carries the LayerNorm
+            if a.tile_n in (256, 64):       # the plan's 256 x 256 x 32 (or 64-column) tile gives way to the kernel that carries the LayerNorm
                 a.tile_n, a.tile_m = pw.tile_n, 0
         else:
             xn = layernorm(x, *ln, out_dtype=pw.dtype)

@@ -461,3 +461,39 @@ def test_layernorm_fold_algebra_of_the_packers():
     wf2, bf2 = ops._fold_ln(w, None, (gamma, beta))
     assert torch.equal(wf2, wf) and torch.allclose(bf2, bf - b, atol=1e-6)
 
+
+
+def test_no_packed_fma_with_a_broadcast_second_source():
+    """A guard on the built library's machine code (needs llvm-objdump, no GPU).  v_pk_fma_f32 with the broadcast operand on
+    its SECOND source (op_sel:[0,1,0]) lost the low product in lanes 48-63 now and then on MI355X when two 8-wave workgroups
+    shared a CU (found with the 128 x 64 tile's LayerNorm-folded epilogue, round 3: csrc/sdmi_gemm_kernel.h lnf_apply); the
+    source forms in use compile to the first-source broadcast, and this test fails if a compiler change brings the other
+    form back anywhere in libsdmi_hip.so."""
+    import struct
+    from stablediffusion_amd import hip
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(hip.LIB_PATH) or not os.path.exists(objdump):
+        pytest.skip("library or llvm-objdump not present")
+    data = open(hip.LIB_PATH, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF", data)][1:]      # (the first header is the host library itself)
+    assert starts, "no gfx950 code objects found in the library"
+    hits, kernels = [], 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, i in enumerate(starts):
+            if data[i + 4] != 2 or struct.unpack_from("<H", data, i + 0x12)[0] != 224:      # ELF64, EM_AMDGPU
+                continue
+            shoff = struct.unpack_from("<Q", data, i + 0x28)[0]
+            shentsize, shnum = struct.unpack_from("<HH", data, i + 0x3A)
+            path = os.path.join(tmp, f"co{n}.elf")
+            with open(path, "wb") as f:
+                f.write(data[i:i + shoff + shentsize * shnum])
+            out = subprocess.run([objdump, "-d", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout
+            name = None
+            for line in out.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+                if m:
+                    name, kernels = m.group(1), kernels + 1
+                elif "v_pk_fma_f32" in line and "op_sel:[0,1,0]" in line:
+                    hits.append((name, line.strip()))
+    assert kernels > 50, kernels
+    assert not hits, hits[:4]

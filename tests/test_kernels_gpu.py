@@ -195,6 +195,143 @@ def test_tall_tile_full_path(dev, monkeypatch):
         assert rel_err(out.permute(0, 3, 1, 2), F.conv2d(xin, q(wt), bias, stride=stride, padding=1)) < 6e-3
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("m,n,k,tile_m", [(512, 1280, 1280, 64), (2048, 640, 640, 128), (130, 320, 1280, 64),
+                                          (1000, 1288, 640, 128), (64, 64, 64, 64), (1, 200, 320, 128)])
+def test_small_tile_64_columns(dev, dt, m, n, k, tile_m, monkeypatch):
+    """sdmi_gemm_args.tile_n = 64 (round 3): 64 x 64 and 128 x 64 blocks for the launches of a few hundred rows (the UNet at
+    batch 1 - 2).  Same k order inside the fp32 accumulation as the larger tiles: unsplit results are bit-identical to the
+    128 x 160 tile's on every epilogue (bias, activation, residual, concat A, embedding rows, K padding, fp32 and 16-bit
+    outputs); split-K and the fp32 reference within rounding; GEGLU, conv and the two-stage ring are refused."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    one = lambda m_, n_, k_, t_=128: 1
+    x, w, b = rnd((m, k), dev, 1), rnd((n, k), dev, 2, k ** -0.5), rnd((n,), dev, 3)
+    res = rnd((m, n), dev, 4)
+    pw = ops.pack_linear(w, b, dtype=dt)
+
+    def both(fn):
+        """fn() on the forced small tile and on the forced 128-row / 160- or 128-column tile, both unsplit"""
+        monkeypatch.setattr(ops, "_auto_split_k", one)
+        monkeypatch.setattr(ops, "FORCE_TILE_N", 64)
+        monkeypatch.setattr(ops, "FORCE_TILE_M", tile_m)
+        small = fn()
+        monkeypatch.setattr(ops, "FORCE_TILE_N", 0)
+        monkeypatch.setattr(ops, "FORCE_TILE_M", 128)
+        large = fn()
+        monkeypatch.setattr(ops, "FORCE_TILE_M", 0)
+        monkeypatch.setattr(ops, "_auto_split_k", ops._AUTO_SPLIT_K)
+        return small, large
+
+    for kw in (dict(res=res.to(dt)), dict(act=1), dict(res=res.to(dt), act=2), dict(out_dtype=torch.float32)):
+        s_, l_ = both(lambda: ops.linear(x.to(dt), pw, **kw))
+        assert torch.equal(s_, l_), kw
+    ref = F.linear(qd(x), qd(w), b)
+    s32, _ = both(lambda: ops.linear(x.to(dt), pw, out_dtype=torch.float32))
+    assert rel_err(s32, ref) < 2e-5 * math.sqrt(k) + 1e-5
+    # split-K on the small tile
+    if k >= 256:
+        monkeypatch.setattr(ops, "FORCE_TILE_N", 64)
+        monkeypatch.setattr(ops, "FORCE_TILE_M", tile_m)
+        monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: 2)
+        sp = ops.linear(x.to(dt), pw, res=res.to(dt), out_dtype=None)
+        monkeypatch.setattr(ops, "_auto_split_k", ops._AUTO_SPLIT_K)
+        monkeypatch.setattr(ops, "FORCE_TILE_N", 0)
+        monkeypatch.setattr(ops, "FORCE_TILE_M", 0)
+        assert rel_err(sp, ref + qd(res)) < (6e-3 if dt == BF16 else 1e-3)
+    # concat A + embedding rows + residual; K padding (k_valid)
+    if k >= 128 and m >= 8:
+        k1 = (k // 128) * 64
+        x1, x2 = x[:, :k1].contiguous().to(dt), x[:, k1:].contiguous().to(dt)
+        rpb = max(m // 4, 1)
+        emb = rnd(((m + rpb - 1) // rpb, n), dev, 5)
+        s_, l_ = both(lambda: ops.linear(x1, pw, x2=x2, emb=emb, rows_per_batch=rpb, res=res.to(dt), out_dtype=torch.float32))
+        assert torch.equal(s_, l_)
+        assert rel_err(s_, ref + qd(res) + emb.repeat_interleave(rpb, dim=0)[:m]) < 2e-5 * math.sqrt(k) + 1e-5
+    kp = k - 24
+    if kp > 0:
+        wp, xp = rnd((n, kp), dev, 6, kp ** -0.5), rnd((m, kp), dev, 7)
+        pwp = ops.pack_linear(wp, b, dtype=dt)
+        s_, l_ = both(lambda: ops.linear(xp.to(dt), pwp, out_dtype=torch.float32))
+        assert torch.equal(s_, l_)
+        assert rel_err(s_, F.linear(qd(xp), qd(wp), b)) < 2e-5 * math.sqrt(k) + 1e-5
+    # refusals through the C ABI: GEGLU, conv, the two-stage ring, a 256-row tile
+    o = torch.empty(m, n, dtype=dt, device=dev)
+    xd = x.to(dt)
+
+    def args():
+        a = ops.hip.GemmArgs()
+        a.mode, a.A, a.lda, a.M, a.W, a.N, a.K = 0, xd.data_ptr(), k, m, pw.w.data_ptr(), n, pw.k
+        a.out, a.ld_out, a.dtype, a.tile_n, a.alpha, a.batch, a.split_k = o.data_ptr(), n, 1 if dt == F16 else 0, 64, 1.0, 1, 1
+        a.k_valid = k if k != pw.k else 0
+        a.bias = pw.bias.data_ptr()
+        return a
+    if n % 8 == 0:
+        a = args()
+        assert ops.hip.lib().sdmi_gemm(C.byref(a), None) == 0
+        torch.cuda.synchronize()
+        assert rel_err(o, ref) < (6e-3 if dt == BF16 else 1e-3)
+    for field, val in (("geglu", 1), ("stages", 2), ("tile_m", 256), ("mode", 1), ("algo", 2)):
+        a = args()
+        if field == "geglu":
+            a.N = (n // 32) * 16 or 16
+        setattr(a, field, val)
+        assert ops.hip.lib().sdmi_gemm(C.byref(a), None) != 0, field
+
+
+def test_small_tile_in_the_token_stream(dev, monkeypatch):
+    """The 64-column tile as a producer and as a consumer of row statistics: a 1280-wide stream written on it carries
+    40 slots per row (one per 32 columns), which the LayerNorm-folded projection reads in three batches."""
+    ops = _ops()
+    m, k, n = 512, 1280, 1280
+    x0 = rnd((m, k), dev, 71).to(F16)
+    w0, b0 = rnd((n, k), dev, 72, 0.03), rnd((n,), dev, 73)
+    r = (rnd((m, n), dev, 74) * 2.0 + 0.7).to(F16)
+    prod = ops.pack_linear(w0, b0, dtype=F16)
+    assert ops._plan_gemm(m, n, k, 160, False, False, True)[3] == 64       # what the UNet's level-2 launches take at batch 2
+    t, (st, slots) = ops.linear(x0, prod, res=r, row_stats=True)
+    assert slots == 40 and st.shape == (m, 40, 2)
+    monkeypatch.setattr(ops, "SMALL_TILE", False)
+    t_l, (st_l, slots_l) = ops.linear(x0, prod, res=r, row_stats=True)
+    monkeypatch.setattr(ops, "SMALL_TILE", True)
+    assert slots_l != 40 and torch.equal(t, t_l)
+    tot, tot_l = st.double().sum(1), st_l.double().sum(1)
+    assert (tot - tot_l).abs().max() < 1e-5 * tot_l.abs().max()
+    gamma, beta = 1.0 + 0.2 * rnd((n,), dev, 75), 0.3 * rnd((n,), dev, 76)
+    ln = (gamma, beta, 1e-5)
+    w1 = rnd((n, n), dev, 77, 0.03)
+    cons = ops.pack_linear(w1, dtype=F16, ln=ln)
+    out = ops.linear(t, cons, ln=ln, stats=(st, slots))              # small tile, folded LayerNorm from 40 slots
+    monkeypatch.setattr(ops, "SMALL_TILE", False)
+    out_l = ops.linear(t, cons, ln=ln, stats=(st_l, slots_l))
+    monkeypatch.setattr(ops, "SMALL_TILE", True)
+    ref = F.linear(F.layer_norm(t.float(), (n,), gamma, beta, 1e-5), w1)
+    assert rel_err(out, ref) < 1.5e-3 and rel_err(out_l, ref) < 1.5e-3
+    assert rel_err(out, out_l.float()) < 1.2e-3
+    # two of these workgroups per CU (a 128 x 64 launch of > 256 blocks), repeated: the folded epilogue once lost the mean
+    # term in a few outputs per launch there (a packed-fma operand form, see lnf_apply) - every launch must agree with the
+    # 128 x 160 tile to rounding
+    for (m2, k2, n2) in ((2100, 640, 1920), (4000, 1280, 1280)):
+        x2 = (rnd((m2, k2), dev, 81) * (0.5 + 2.0 * torch.rand(m2, 1, device=dev)) + 1.5 * rnd((m2, 1), dev, 82)).to(F16)
+        g2, b2 = 1.0 + 0.2 * rnd((k2,), dev, 83), 0.3 * rnd((k2,), dev, 84)
+        pw2 = ops.pack_linear(rnd((n2, k2), dev, 85, 0.06), rnd((n2,), dev, 86), dtype=F16, ln=(g2, b2, 1e-5))
+        st2 = ops.row_stats_of(x2)
+        monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: 1)
+        monkeypatch.setattr(ops, "FORCE_TILE_M", 128)
+        want = ops.linear(x2, pw2, ln=(g2, b2, 1e-5), stats=st2).float()
+        monkeypatch.setattr(ops, "FORCE_TILE_N", 64)
+        for _ in range(20):
+            got = ops.linear(x2, pw2, ln=(g2, b2, 1e-5), stats=st2).float()
+            assert (got - want).abs().max() < 2e-2
+        monkeypatch.setattr(ops, "FORCE_TILE_N", 0)
+        monkeypatch.setattr(ops, "FORCE_TILE_M", 0)
+        monkeypatch.setattr(ops, "_auto_split_k", ops._AUTO_SPLIT_K)
+    # a stream too wide for 48 slots keeps the larger tiles
+    wide_w = ops.pack_linear(rnd((1920, 320), dev, 78, 0.05), dtype=F16)
+    _, (st_w, slots_w) = ops.linear(rnd((256, 320), dev, 79).to(F16), wide_w, row_stats=True)
+    assert slots_w <= 48
+
+
 @pytest.mark.parametrize("dt", [BF16, F16])
 def test_wide_tile_256x256x32(dev, dt, monkeypatch):
     """The 256 x 256 x 32 tile (sdmi_gemm_wide.h, tile_n = 256) against the fp32 reference and against the tiled kernel

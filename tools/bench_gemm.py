@@ -9,6 +9,7 @@ from stablediffusion_amd import ops
 
 dev = torch.device("cuda:0")
 ops.FORCE_WIDE = int(os.environ.get("WIDE", "0"))      # 1 = the 256 x 256 x 32 tile where it applies
+ops.FORCE_TILE_N = 64 if os.environ.get("TILE_N") == "64" else 0      # the small tile (with TILE_M=64|128 or CONFIGS=64:1,128:1)
 ops.FORCE_ALGO = int(os.environ.get("ALGO", "0"))      # 1 = tiled kernel only, 2 = panel kernel (fails where it does not apply)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else None
