@@ -45,7 +45,7 @@ typedef enum sdmi_dtype {
 } sdmi_dtype;
 
 const char* sdmi_status_str(int status);
-int sdmi_abi_version(void);   /* 12: + sdmi_gemm_args.ln_colsum / ln_stats / row_stats_out (LayerNorm folded into the projection, row statistics travelling with the residual stream), sdmi_gemm_row_stats_slots, sdmi_row_stats, sdmi_xattn_block (the cross-attention half of a transformer block as one launch); 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
+int sdmi_abi_version(void);   /* 13: + sdmi_gemm_args.tile_n == 64 (the 64-column tile, tile_m 64 | 128), ln_stats_slots up to 48; 12: + sdmi_gemm_args.ln_colsum / ln_stats / row_stats_out (LayerNorm folded into the projection, row statistics travelling with the residual stream), sdmi_gemm_row_stats_slots, sdmi_row_stats, sdmi_xattn_block (the cross-attention half of a transformer block as one launch); 11: + sdmi_gemm_args.out_f16 / res_f16 / a_f16 / dup_rows, SDMI_DTYPE_F16_TO_BF16, sdmi_probe_mfma, sdmi_probe_copy (measurement aids); 10: + sdmi_gemm_args.tile_n == 256, sdmi_gemm_wide_applies; 9: + sdmi_f32_attention_vae, sdmi_f32_nchw_to_nhwc takes a scale; 8: + sdmi_gemm_args.ln_gamma/ln_beta/ln_eps, sdmi_gemm_panel_applies; 7: + sdmi_gemm_args.algo; 6: + sdmi_attention_vae; 5: + sdmi_pack_*; 4: + sdmi_groupnorm_noalloc, SDMI_ERR_TOO_LARGE (3: + sdmi_f32_embed_tokens,
                                  sdmi_f32_attention_d64_causal, sdmi_gemm_args.act == 2; 2: dtype, fp32 mode) */
 
 /* ------------------------------------------------------------------------------------------
@@ -101,8 +101,15 @@ typedef struct sdmi_gemm_args {
     int32_t tile_n;                     /* column tile of the kernel: 128 (0 = 128) or 160; W rows padded to it.  256 = the
                                            256 x 256 x 32 tile (more FLOP per byte moved into LDS: for long K with N_w a
                                            multiple of 256): the caller vouches that W has N_w rounded up to 256 rows, and
-                                           sdmi_gemm_wide_applies() must hold - SDMI_ERR_BAD_ARG otherwise */
-    int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 */
+                                           sdmi_gemm_wide_applies() must hold - SDMI_ERR_BAD_ARG otherwise.
+                                           64 = the small tile (mode 0; 64 columns x tile_m = 128 | 64 rows, three stages): for
+                                           launches of a few hundred rows, where the larger tiles leave most CUs without a block
+                                           (the UNet at batch 1 - 2: 512 x 1280 x 1280 18.0 -> 9.7 us); W must hold N_w rounded up
+                                           to 64 rows (any buffer packed for 128 | 160 with N_w % 64 == 0 does); no GEGLU, no
+                                           ln_gamma, algo != 2, stages != 2 - SDMI_ERR_BAD_ARG otherwise.  Same k order inside
+                                           the fp32 sums as the larger tiles: unsplit results are bit-identical */
+    int32_t tile_m;                     /* row tile: 0 = sdmi_gemm_tile_m() picks, or 128 | 256 (tile_n 128 | 160), 256 (tile_n
+                                           256), 64 | 128 (tile_n 64) */
     int32_t asym_pad;                   /* mode 1: 0 = zero pad 1 on every side; 1 = pad bottom/right only - the VAE
                                            encoder's DownSample, F.pad(x, (0,1,0,1)) + conv stride 2 (model.py:87,99-102) */
     int32_t res_f32;                    /* 1: `res` is fp32 (only with an fp32 out_kind) - the fp32 mode of the path */
@@ -141,15 +148,15 @@ typedef struct sdmi_gemm_args {
        LayerNorm(a) @ W^T + bias = rstd[m] * (a @ W'^T - mean[m] * colsum[n]) + bias'[n]: the kernel multiplies the RAW rows
        of A and applies two numbers per row in front of the usual epilogue (with split_k > 1: in the reduce pass).  They come
        from ln_stats [M][ln_stats_slots][2] = per row and slot the partial (sum a, sum a^2) over the row's K columns (biased
-       variance, fp32, eps = ln_eps; ln_stats_slots even and <= 32, or 1 | 3; 16-byte aligned) - left there by the launch that PRODUCED A
+       variance, fp32, eps = ln_eps; ln_stats_slots even and <= 48, or 1 | 3; 16-byte aligned) - left there by the launch that PRODUCED A
        through row_stats_out, or by sdmi_row_stats. */
     const float* ln_colsum;
     const float* ln_stats;
     int32_t ln_stats_slots;
     /* row_stats_out non-NULL: besides storing `out`, the launch leaves the row sums of the values it stores (fp32, before
        the rounding to f16) in row_stats_out [M (2 M with dup_rows)][row_stats_slots][2]; row_stats_slots must equal
-       sdmi_gemm_row_stats_slots(args) (one slot per (column tile, wave column) of the kernel the plan in args selects; one per
-       1024 columns with split_k > 1).  16-bit row-major output with the conditions of dup_rows (split_k > 1 allowed without dup_rows), no GEGLU.
+       sdmi_gemm_row_stats_slots(args) (one slot per (column tile, wave column) of the kernel the plan in args selects - two
+       per 128 | 160 | 64 columns, four per 256 -; one per 1024 columns with split_k > 1; at most 48: what a consumer reads).  16-bit row-major output with the conditions of dup_rows (split_k > 1 allowed without dup_rows), no GEGLU.
        This is how to_out + residual, the feed-forward's second linear and proj_in hand the statistics of the residual
        stream to the LayerNorm-folded projection that reads it next. */
     int32_t row_stats_slots;
@@ -171,7 +178,7 @@ int32_t sdmi_gemm_row_stats_slots(const sdmi_gemm_args* args);
    launch with row_stats_out (the reference has no counterpart: its nn.LayerNorm computes them on the fly).  C % 8 == 0. */
 int sdmi_row_stats(const void* x, float* stats, int64_t rows, int32_t C, int32_t dtype, void* stream);
 int64_t sdmi_gemm_workspace_bytes(int64_t M, int64_t N_w, int32_t split_k);
-/* Row tile (128 | 256) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
+/* Row tile (128 | 256; 64 | 128 for tile_n = 64) sdmi_gemm uses for this problem when args.tile_m == 0 (for split-K planning). */
 int32_t sdmi_gemm_tile_m(int64_t M, int64_t N_w, int32_t tile_n);
 
 /* ------------------------------------------------------------------------------------------

@@ -13,4 +13,4 @@ extern "C" const char* sdmi_status_str(int status) {
     }
 }
 
-extern "C" int sdmi_abi_version(void) { return 12; }
+extern "C" int sdmi_abi_version(void) { return 13; }

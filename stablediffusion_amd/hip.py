@@ -52,7 +52,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 12    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
+ABI_VERSION = 13    # sdmi_abi_version() of the library this binding was written against (include/sdmi.h)
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Aggregate a rocprofv3 kernel_trace CSV by (kernel name, grid, workgroup): usage summarize_trace.py <dir-or-csv> [skip_first_n_dispatches]
+"""Aggregate a rocprofv3 kernel_trace CSV by (kernel name, grid, workgroup): usage summarize_trace.py <dir-or-csv> [skip_first_n_dispatches | -last_n]
 Prints calls, total and average duration per group, sorted by total time, and the sum of the gaps between consecutive
 dispatches (end -> next start)."""
 import csv, glob, os, sys
@@ -11,7 +11,7 @@ if os.path.isdir(path):
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rows = rows[skip:]
+rows = rows[skip:]      # (negative: the last -skip dispatches only, e.g. the steps behind the model build)
 agg = {}
 for r in rows:
     name = r["Kernel_Name"]
