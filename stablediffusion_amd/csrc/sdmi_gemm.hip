@@ -154,9 +154,9 @@ int sdmi_gemm_wide_attrs_f16_lnf();
 int sdmi_gemm_small_attrs_m0_bf16();                                     // the 64-column tile (mode 0): sdmi_gemm_m0_*.hip, sdmi_gemm_lnf.hip
 int sdmi_gemm_small_attrs_m0_f16();
 int sdmi_gemm_small_attrs_m0_f16_lnf();
-void sdmi_gemm_small_launch_m0_bf16(int which, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
-void sdmi_gemm_small_launch_m0_f16(int which, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
-void sdmi_gemm_small_launch_m0_f16_lnf(int which, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_small_launch_m0_bf16(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_small_launch_m0_f16(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_small_launch_m0_f16_lnf(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 void sdmi_gemm_wide_launch_f16_lnf(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_wide_attrs_bf16();                                         // sdmi_gemm_wide_*.hip
 int sdmi_gemm_wide_attrs_f16();
@@ -275,9 +275,6 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         // no LayerNorm on resident rows (the panel kernel's)
         if (p.mode != 0 || p.geglu || p.ln_gamma != nullptr || p.algo == 2 || p.stages == 2) return SDMI_ERR_BAD_ARG;
         if (p.tile_m != 0 && p.tile_m != 64 && p.tile_m != 128) return SDMI_ERR_BAD_ARG;
-    } else if (p.tile_m == 64) {
-        // 64 rows x 128 columns: the small tile GEGLU can take (mode 0, three stages, not the panel kernel)
-        if (BN != 128 || p.mode != 0 || p.ln_gamma != nullptr || p.algo == 2 || p.stages == 2) return SDMI_ERR_BAD_ARG;
     } else if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
     if (p.stages != 0 && p.stages != 2 && p.stages != 3) return SDMI_ERR_BAD_ARG;
     if (BN == 256 && !wide_applies(p)) return SDMI_ERR_BAD_ARG;
@@ -364,10 +361,9 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (BN == 64 || BM == 64) {
-        const int which = BN == 128 ? 2 : (BM == 64 ? 1 : 0);
-        if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) sdmi_gemm_small_launch_m0_f16_lnf(which, grid, s, p);
-        else (f16 ? sdmi_gemm_small_launch_m0_f16 : sdmi_gemm_small_launch_m0_bf16)(which, grid, s, p);
+    if (BN == 64) {
+        if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) sdmi_gemm_small_launch_m0_f16_lnf(BM == 64, grid, s, p);
+        else (f16 ? sdmi_gemm_small_launch_m0_f16 : sdmi_gemm_small_launch_m0_bf16)(BM == 64, grid, s, p);
     } else if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) {
         if (BN == 256) sdmi_gemm_wide_launch_f16_lnf(0, grid, s, p);
         else           sdmi_gemm_unit_launch_m0_f16_lnf(wide, tall ? 1 : 0, grid, s, p);

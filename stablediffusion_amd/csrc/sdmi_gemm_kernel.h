@@ -996,23 +996,24 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                            lds_bytes(wide ? 5 : 4, variant == 1 ? 4 : 2, 3), s, p);                                 \
     }
 
-// The small tiles (mode 0, three stages): [0] = 128 rows x 64 columns, [1] = 64 x 64, [2] = 64 rows x 128 columns (the one
-// GEGLU can take: a wave holds two (value, gate) pairs of 16-column blocks; 72 KiB of LDS, two workgroups per CU).
+// The small tile (64 columns; 128 | 64 rows; three stages; mode 0): [0] = 128 rows, [1] = 64 rows.
+// (A 64-row x 128-column variant for the GEGLU projections - two workgroups per CU, one block's erf epilogue under the
+// other's k-steps - was built and measured: 8192 x 2560 x 320 29.4 -> 33.1 us, 2048 x 5120 x 640 24.8 -> 24.3, 512 x 10240 x
+// 1280 21.7 -> 25.3, and 25-40 % slower from 4096 rows on: these launches are bound by the bytes a CU pulls into LDS, which a
+// smaller tile only adds to.  Not kept.)
 #define SDMI_GEMM_UNIT_SMALL(DT, LNF, NAME)                                                                         \
     namespace {                                                                                                     \
     typedef void (*small_kern_t_##NAME)(const sdmi_gemm_args);                                                      \
-    const small_kern_t_##NAME small_kernels_##NAME[3] = {sdmi_gemm_kernel<0, DT, 2, 2, 3, LNF>,                     \
-                                                         sdmi_gemm_kernel<0, DT, 2, 1, 3, LNF>,                     \
-                                                         sdmi_gemm_kernel<0, DT, 4, 1, 3, LNF>};                    \
-    constexpr int small_lds_##NAME[3] = {lds_bytes(2, 2, 3), lds_bytes(2, 1, 3), lds_bytes(4, 1, 3)};               \
+    const small_kern_t_##NAME small_kernels_##NAME[2] = {sdmi_gemm_kernel<0, DT, 2, 2, 3, LNF>,                     \
+                                                         sdmi_gemm_kernel<0, DT, 2, 1, 3, LNF>};                    \
     }                                                                                                               \
     int sdmi_gemm_small_attrs_##NAME() {                                                                            \
-        for (int d = 0; d < 3; ++d)                                                                                 \
+        for (int d = 0; d < 2; ++d)                                                                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_kernels_##NAME[d]),                         \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_##NAME[d]) != hipSuccess) \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, d ? 1 : 2, 3)) != hipSuccess) \
                 return SDMI_ERR_LAUNCH;                                                                             \
         return SDMI_OK;                                                                                             \
     }                                                                                                               \
-    void sdmi_gemm_small_launch_##NAME(int which, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {              \
-        hipLaunchKernelGGL(small_kernels_##NAME[which], grid, dim3(512), small_lds_##NAME[which], s, p);            \
+    void sdmi_gemm_small_launch_##NAME(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {             \
+        hipLaunchKernelGGL(small_kernels_##NAME[rows64 ? 1 : 0], grid, dim3(512), lds_bytes(2, rows64 ? 1 : 2, 3), s, p); \
     }

@@ -73,31 +73,3 @@ for dt in ((F16,) if os.environ.get('F16_ONLY') else (F16, torch.bfloat16)):
                 line += f" | {tm}x64/{sk} {t1:5.1f} us d={d:.1e} s={ds}"
         print(line, flush=True)
 
-# GEGLU projections on the 64-row x 128-column tile (two workgroups per CU: one block's erf epilogue under the other's
-# k-steps) against the planned launch; plain and LayerNorm-folded weights
-print("GEGLU (m, inner, k): plan | 64 x 128", flush=True)
-for (m, inner, k) in ((8192, 1280, 320), (2048, 2560, 640), (512, 5120, 1280), (128, 5120, 1280), (4096, 5120, 1280), (16384, 2560, 640)):
-    x = torch.randn(m, k, device=dev).to(F16)
-    w, b = torch.randn(2 * inner, k, device=dev) * 0.03, torch.randn(2 * inner, device=dev)
-    gamma, beta = 1.0 + 0.2 * torch.randn(k, device=dev), 0.3 * torch.randn(k, device=dev)
-    for name, pw, kw in (("plain", ops.pack_geglu(w, b, dtype=F16), {}),
-                         ("folded", ops.pack_geglu(w, b, dtype=F16, ln=(gamma, beta, 1e-5)), dict(ln=(gamma, beta, 1e-5), stats=ops.row_stats_of(x)))):
-        ops.FORCE_TILE_N = ops.FORCE_TILE_M = 0
-        saved = ops.fold_applies
-        ops.fold_applies = lambda pw_, rows_: True
-        base = ops.linear(x, pw, **kw)
-        t0 = timed(lambda: ops.linear(x, pw, **kw))
-        ops.FORCE_TILE_M = 64
-        line = f"geglu {name:6s} {m:6d} {inner:5d} {k:5d}  plan {t0:6.1f} us"
-        for sk in (1, 2):
-            ops._auto_split_k = lambda m_, n_, k_, t=128, s_=sk: s_
-            try:
-                out = ops.linear(x, pw, **kw)
-                t1 = timed(lambda: ops.linear(x, pw, **kw))
-                line += f" | 64x128/{sk} {t1:6.1f} us d={(out.float() - base.float()).abs().max().item():.1e}"
-            except ops.hip.SdmiError as e:
-                line += f" | 64x128/{sk} n/a"
-            ops._auto_split_k = ops._AUTO_SPLIT_K
-        ops.FORCE_TILE_M = 0
-        ops.fold_applies = saved
-        print(line, flush=True)
