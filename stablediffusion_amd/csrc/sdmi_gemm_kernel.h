@@ -11,6 +11,10 @@
 #define SDMI_SETPRIO 0   // A/B on MI355X (tools/ab_build.sh): raising the wave priority around the MFMA groups gains nothing here
 #endif
 
+#ifndef SDMI_DEBUG_A_FILL_NINTH
+#define SDMI_DEBUG_A_FILL_NINTH 0   // timing experiment only (results wrong, ring waits under-counted): the conv's A tile is moved into LDS on every ninth k-tile only - the LDS fill bytes of a halo-tile kernel (each input pixel staged once per channel chunk instead of once per tap) with everything else unchanged
+#endif
+
 namespace {
 
 // Zeros: the DMA source of out-of-image conv taps and padded rows / columns (the DMA cannot mask).  Long enough
@@ -651,8 +655,9 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
                 SDMI_TAP_PTR(0, ky_, kx_); SDMI_TAP_PTR(1, ky_, kx_);                                      \
                 if (NA == 4) { SDMI_TAP_PTR(NA - 2, ky_, kx_); SDMI_TAP_PTR(NA - 1, ky_, kx_); }           \
             }                                                                                              \
-            if (NA == 4) glds_v4<0>(d0_, a_ptr[0], a_ptr[1], a_ptr[NA - 2], a_ptr[NA - 1]);                \
-            else         glds_v2<0>(d0_, a_ptr[0], a_ptr[1]);                                              \
+            if (SDMI_DEBUG_A_FILL_NINTH && ((KT) % 9) != 0) { /* timing experiment: see the macro */ }           \
+            else if (NA == 4) glds_v4<0>(d0_, a_ptr[0], a_ptr[1], a_ptr[NA - 2], a_ptr[NA - 1]);           \
+            else              glds_v2<0>(d0_, a_ptr[0], a_ptr[1]);                                         \
             _Pragma("unroll")                                                                              \
             for (int i_ = 0; i_ < NA; ++i_) a_ptr[i_] += BK;                                               \
             f_ci += BK;                                                                                    \

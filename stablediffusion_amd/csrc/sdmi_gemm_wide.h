@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void sdmi_gemm_wide_kernel(const sdmi_gemm_
                 const int ky_ = f_tap / 3, kx_ = f_tap - 3 * ky_;                                          \
                 SDMI_W_TAP_PTR(0, ky_, kx_); SDMI_W_TAP_PTR(1, ky_, kx_);                                  \
             }                                                                                              \
-            glds_v2<0>(d0_, a_ptr[0], a_ptr[1]);                                                           \
+            if (!(SDMI_DEBUG_A_FILL_NINTH && ((KT) % 9) != 0)) glds_v2<0>(d0_, a_ptr[0], a_ptr[1]);        \
             a_ptr[0] += WBK; a_ptr[1] += WBK;                                                              \
             f_ci += WBK;                                                                                   \
             f_new_tap = f_ci == p.Cin;                                                                     \

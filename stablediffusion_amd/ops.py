@@ -210,7 +210,9 @@ def fold_applies(pw, rows):
         return False
     if pw.plain is None:
         return True
-    if pw.geglu and rows >= FOLD_MAX_ROWS_GEGLU:
+    if pw.geglu and rows >= FOLD_MAX_ROWS_GEGLU and not (pw.k == 320 and rows <= 8192):
+        # (the level-0 GEGLU projection at UNet batch 2 - 8192 x 2560 x 320 - is below the panel kernel's 16384 rows, so its
+        # unfolded form pays a LayerNorm launch: 29.4 + 8.2 us and a launch boundary against 32.2 us folded)
         return False
     if pw.k == 320 and rows >= FOLD_MAX_ROWS_PANEL and (pw.geglu or pw.n_out == 960):
         return False

@@ -435,6 +435,8 @@ def test_fold_policy_of_layernorm_consuming_projections():
     assert ops.fold_applies(mk(plain=None, geglu=True), 1 << 20)
     assert ops.fold_applies(mk(geglu=True), 2048) and not ops.fold_applies(mk(geglu=True), 4096)
     assert ops.fold_applies(mk(k=320, n_out=960), 8192) and not ops.fold_applies(mk(k=320, n_out=960), 16384)
+    # the level-0 GEGLU projection below the panel kernel's rows (UNet batch 2: 8192 rows) stays folded
+    assert ops.fold_applies(mk(geglu=True, k=320, n_out=1280), 8192) and not ops.fold_applies(mk(geglu=True, k=320, n_out=1280), 16384)
     assert ops.fold_applies(mk(k=320, n_out=320), 65536) and ops.fold_applies(mk(), 65536)
 
 
