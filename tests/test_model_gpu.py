@@ -570,6 +570,23 @@ def test_hip_graph_replay_is_bit_identical(dev):
     b, _ = g.sample(x_T=x_T * 0.5, **kw)
     b_eager, _ = DDIMSampler(model).sample(x_T=x_T * 0.5, **kw)
     assert torch.equal(a, eager) and torch.equal(b, b_eager) and not torch.equal(a, b)
+    # a new prompt does not re-capture: the conditioning is a static input of the graph and the UNet's cross-attention
+    # K / V are re-projected into the tensor the captured launches read (UNetModel.refresh_context_kv)
+    graph_obj = g._apply._graph
+    c2 = torch.randn(2, 7, 96, generator=torch.Generator().manual_seed(8)).to(dev)
+    kw2 = dict(kw, conditioning=c2)
+    d, _ = g.sample(x_T=x_T, **kw2)
+    d_eager, _ = DDIMSampler(model).sample(x_T=x_T, **kw2)
+    assert g._apply._graph is graph_obj
+    assert torch.equal(d, d_eager) and not torch.equal(d, a)
+    # ... and the first prompt again, after the eager sampler above replaced the UNet's own cache entry
+    a2, _ = g.sample(x_T=x_T, **kw)
+    assert g._apply._graph is graph_obj and torch.equal(a2, eager)
+    # a prompt edited in place (same tensor, new version) is seen as well
+    c2.mul_(0.5)
+    e, _ = g.sample(x_T=x_T, **kw2)
+    e_eager, _ = DDIMSampler(model).sample(x_T=x_T, **kw2)
+    assert torch.equal(e, e_eager) and not torch.equal(e, d)
 
 
 FP32_GATE = 1e-5       # BASELINE north_star: per-step eps/v max relative error <= 1e-5 in fp32 mode
