@@ -102,7 +102,7 @@ typedef struct sdmi_gemm_args {
                                            256 x 256 x 32 tile (more FLOP per byte moved into LDS: for long K with N_w a
                                            multiple of 256): the caller vouches that W has N_w rounded up to 256 rows, and
                                            sdmi_gemm_wide_applies() must hold - SDMI_ERR_BAD_ARG otherwise.
-                                           64 = the small tile (mode 0; 64 columns x tile_m = 128 | 64 rows, three stages): for
+                                           64 = the small tile (64 columns x tile_m = 128 | 64 rows - mode 1: 128 only -, three stages): for
                                            launches of a few hundred rows, where the larger tiles leave most CUs without a block
                                            (the UNet at batch 1 - 2: 512 x 1280 x 1280 18.0 -> 9.7 us); W must hold N_w rounded up
                                            to 64 rows (any buffer packed for 128 | 160 with N_w % 64 == 0 does); no GEGLU, no

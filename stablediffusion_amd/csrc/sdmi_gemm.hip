@@ -157,6 +157,10 @@ int sdmi_gemm_small_attrs_m0_f16_lnf();
 void sdmi_gemm_small_launch_m0_bf16(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 void sdmi_gemm_small_launch_m0_f16(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 void sdmi_gemm_small_launch_m0_f16_lnf(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+int sdmi_gemm_small_conv_attrs_m1_bf16();                                // conv3x3 on the 128 x 64 block: sdmi_gemm_m1_*.hip
+int sdmi_gemm_small_conv_attrs_m1_f16();
+void sdmi_gemm_small_conv_launch_m1_bf16(dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
+void sdmi_gemm_small_conv_launch_m1_f16(dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 void sdmi_gemm_wide_launch_f16_lnf(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_wide_attrs_bf16();                                         // sdmi_gemm_wide_*.hip
 int sdmi_gemm_wide_attrs_f16();
@@ -273,12 +277,13 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     if (BN == 64) {
         // the small tile: mode 0, 64 columns x 128 | 64 rows, three stages; no GEGLU (a wave holds two 16-column blocks),
         // no LayerNorm on resident rows (the panel kernel's)
-        if (p.mode != 0 || p.geglu || p.ln_gamma != nullptr || p.algo == 2 || p.stages == 2) return SDMI_ERR_BAD_ARG;
+        if (p.geglu || p.ln_gamma != nullptr || p.algo == 2 || p.stages == 2) return SDMI_ERR_BAD_ARG;
         if (p.tile_m != 0 && p.tile_m != 64 && p.tile_m != 128) return SDMI_ERR_BAD_ARG;
+        if (p.mode == 1 && p.tile_m == 64) return SDMI_ERR_BAD_ARG;      // (the conv loader stages two 64-row pieces of A)
     } else if (p.tile_m != 0 && p.tile_m != 128 && p.tile_m != 256) return SDMI_ERR_BAD_ARG;
     if (p.stages != 0 && p.stages != 2 && p.stages != 3) return SDMI_ERR_BAD_ARG;
     if (BN == 256 && !wide_applies(p)) return SDMI_ERR_BAD_ARG;
-    const int BM = BN == 256 ? 256 : p.tile_m != 0 ? p.tile_m : pick_tile_m(p.M, n_w, BN, batch);
+    const int BM = BN == 256 ? 256 : p.tile_m != 0 ? p.tile_m : (BN == 64 && p.mode == 1) ? 128 : pick_tile_m(p.M, n_w, BN, batch);
     const int64_t tiles_m = (p.M + BM - 1) / BM, tiles_n = (n_w + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return SDMI_ERR_BAD_ARG;
     if (split > 1) {
@@ -353,7 +358,8 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
         for (int i = 0; i < 4; ++i) ok = (fns[i]() == SDMI_OK) && ok;
         ok = (sdmi_gemm_unit_attrs_m0_f16_lnf() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16_lnf() == SDMI_OK) && ok;
         ok = (sdmi_gemm_small_attrs_m0_bf16() == SDMI_OK) && (sdmi_gemm_small_attrs_m0_f16() == SDMI_OK) &&
-             (sdmi_gemm_small_attrs_m0_f16_lnf() == SDMI_OK) && ok;
+             (sdmi_gemm_small_attrs_m0_f16_lnf() == SDMI_OK) && (sdmi_gemm_small_conv_attrs_m1_bf16() == SDMI_OK) &&
+             (sdmi_gemm_small_conv_attrs_m1_f16() == SDMI_OK) && ok;
         return (sdmi_gemm_wide_attrs_bf16() == SDMI_OK) && (sdmi_gemm_wide_attrs_f16() == SDMI_OK) && ok;
     });
     if (attr_status != SDMI_OK) return attr_status;
@@ -361,7 +367,9 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (BN == 64) {
+    if (BN == 64 && p.mode == 1) {
+        (f16 ? sdmi_gemm_small_conv_launch_m1_f16 : sdmi_gemm_small_conv_launch_m1_bf16)(grid, s, p);
+    } else if (BN == 64) {
         if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) sdmi_gemm_small_launch_m0_f16_lnf(BM == 64, grid, s, p);
         else (f16 ? sdmi_gemm_small_launch_m0_f16 : sdmi_gemm_small_launch_m0_bf16)(BM == 64, grid, s, p);
     } else if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) {

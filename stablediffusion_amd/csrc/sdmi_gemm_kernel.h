@@ -492,7 +492,7 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     constexpr int NW = BN / RPI;                // W instructions every thread issues (2 | 1)
     static_assert(NA == 4 || NA == 2 || NA == 1, "row tile");
     static_assert(NW == 2 || NW == 1, "column tile");
-    static_assert(MODE == 0 || (NA >= 2 && NW == 2), "the small tile is built for mode 0 only");
+    static_assert(MODE == 0 || NA >= 2, "the conv loader stages two or four 64-row pieces of A");
     constexpr bool W_TAIL = (BN % RPI) != 0;    // leftover 32 W rows (TN = 5): waves 0..3 issue one more
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint4* const lds = reinterpret_cast<const uint4*>(smem);
@@ -1021,4 +1021,15 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     }                                                                                                               \
     void sdmi_gemm_small_launch_##NAME(int rows64, dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {             \
         hipLaunchKernelGGL(small_kernels_##NAME[rows64 ? 1 : 0], grid, dim3(512), lds_bytes(2, rows64 ? 1 : 2, 3), s, p); \
+    }
+
+// conv3x3 on the 128 x 64 block (mode 1; the few-hundred-row convs of the UNet at batch 1 - 2)
+#define SDMI_GEMM_UNIT_SMALL_CONV(DT, NAME)                                                                         \
+    int sdmi_gemm_small_conv_attrs_##NAME() {                                                                       \
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(sdmi_gemm_kernel<1, DT, 2, 2, 3>),                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2, 2, 3)) == hipSuccess    \
+                   ? SDMI_OK : SDMI_ERR_LAUNCH;                                                                     \
+    }                                                                                                               \
+    void sdmi_gemm_small_conv_launch_##NAME(dim3 grid, hipStream_t s, const sdmi_gemm_args& p) {                    \
+        hipLaunchKernelGGL((sdmi_gemm_kernel<1, DT, 2, 2, 3>), grid, dim3(512), lds_bytes(2, 2, 3), s, p);          \
     }

@@ -328,7 +328,7 @@ def _wide_wins(m, n_w, nk, tile_n):
 
 
 @functools.lru_cache(maxsize=None)
-def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False, small_ok=False):
+def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False, small_ok=False, conv=False):
     """(tile_m, split_k, stages, tile_n) from a small occupancy model, in microseconds.  A launch of B blocks puts
     ceil(B/256) blocks on the busiest CU one after the other; a block costs nk/s k-tile steps plus a fixed
     prologue/epilogue; splitting K adds the fp32 slab write + the reduce pass.  Step times fitted to
@@ -362,7 +362,7 @@ def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False, small_ok=False
                 cost += (2 * s + 0.5) * m * n_w * 4 / 12.0e6 + 6.0   # slab write+read (mostly L2/MALL) + the extra launch
             if best_cost is None or cost < best_cost * 0.97:
                 best, best_cost = (tile_m, s, 3, tile_n), cost
-    if small_ok:
+    if small_ok and not conv:
         # The 64-column tile (round 3): 64 x 64 or 128 x 64 blocks for launches whose larger tiles leave most CUs without a
         # block (a few hundred rows: the UNet at batch 1 - 2, the 8 x 8 level at any batch).  Unsplit only - every split
         # measured slower than the unsplit small tile (tools/small_tile_check.py, hipGraph replay, in the units of the
@@ -375,6 +375,22 @@ def _plan_gemm(m, n_w, k, tile_n=_BN, wide_ok=False, geglu=False, small_ok=False
             cost = max(step_us * nk + fixed, 0.5) + (rounds - 1) * (step_us * nk + 1.5)
             if cost < best_cost * 0.95:
                 best, best_cost = (tile_m, 1, 3, 64), cost
+    if small_ok and conv and m <= 8192:
+        # conv3x3 on the 128 x 64 block (tools/small_conv_check.py, hipGraph replay): 0.35 us a k-tile while every block has
+        # a CU to itself, x 1.6 with two co-resident blocks per CU; the split costs are those of the larger tiles.  It wins
+        # where the 160-column tiles leave CUs idle even with their best split: 8 x 8 x 1280 at UNet batch 2 (128 rows)
+        # 21.8 (split 14) -> 17.5 us (split 12), 64 x 64 x 320 (8192 rows) 33.7 (split 2 + reduce) -> 29.5 unsplit; it loses
+        # from 512 rows x 1280 columns on, where the model below keeps the larger tiles.
+        tiles = math.ceil(m / 128) * math.ceil(n_w / 64)
+        for s in range(1, 25 if m <= 256 else 2):      # (split only where it was measured to win: one or two row tiles)
+            if s > 1 and nk // s < 2:
+                break
+            blocks = tiles * s
+            cost = 0.35 * math.ceil(nk / s) * (1.0 if blocks <= _CUS else 0.8 * math.ceil(blocks / _CUS))
+            if s > 1:
+                cost += (2 * s + 0.5) * m * n_w * 4 / 12.0e6 + 6.0
+            if cost < best_cost * 0.95:
+                best, best_cost = (128, s, 3, 64), cost
     return best
 
 
@@ -478,9 +494,9 @@ def _fill_common(a, pw, out, bias_on, emb, rows_per_batch, res, act, out_kind, a
         a.tile_n, a.split_k = 256, 1
         wide_ok = bool(hip.lib().sdmi_gemm_wide_applies(C.byref(a)))
     # the 64-column tile (mode 0, no GEGLU): the packed weight must hold whole 64-row tiles
-    small_ok = bool(allow_small and a.mode == 0 and not pw.geglu and not FORCE_ALGO and pw.w.shape[0] >= _round_up(n_w, 64))
+    small_ok = bool(allow_small and not pw.geglu and not FORCE_ALGO and pw.w.shape[0] >= _round_up(n_w, 64))
     a.tile_m, sk, a.stages, a.tile_n = _plan_gemm(m, n_w, pw.k, pw.tile_n, wide_ok, bool(pw.geglu),
-                                                  small_ok and SMALL_TILE and not FORCE_TILE_M)
+                                                  small_ok and SMALL_TILE and not FORCE_TILE_M, conv=a.mode == 1)
     if FORCE_WIDE and wide_ok:
         a.tile_m, sk, a.tile_n = 256, 1, 256
     if _auto_split_k is not _AUTO_SPLIT_K or a.tile_n not in (256, 64):

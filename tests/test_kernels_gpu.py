@@ -279,6 +279,46 @@ def test_small_tile_64_columns(dev, dt, m, n, k, tile_m, monkeypatch):
         assert ops.hip.lib().sdmi_gemm(C.byref(a), None) != 0, field
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,ups", [(2, 8, 8, 1280, 1280, 1, False), (1, 20, 12, 64, 320, 1, False),
+                                                        (2, 16, 16, 128, 192, 2, False), (1, 8, 8, 128, 64, 1, True),
+                                                        (1, 16, 16, 8, 320, 1, False)])
+def test_small_tile_conv3x3(dev, dt, b, h, w, cin, cout, stride, ups, monkeypatch):
+    """conv3x3 on the 128 x 64 block (tile_n = 64, mode 1): bit-identical to the 128-row / 160- or 128-column tile unsplit
+    (bias + embedding rows + residual epilogue, stride 2, fused nearest x 2 upsampling, the general loader of conv_in),
+    split-K and torch's conv2d within rounding; what the plan takes for the one-row-tile convs of the UNet at batch 2."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    x = rnd((b, cin, h, w), dev, 31)
+    wt, bias = rnd((cout, cin, 3, 3), dev, 32, (9 * cin) ** -0.5), rnd((cout,), dev, 33)
+    xi = x.permute(0, 2, 3, 1).contiguous().to(dt)
+    pw = ops.pack_conv3x3(wt, bias, dtype=dt)
+    ho, wo = (h * (2 if ups else 1) + 2 - 3) // stride + 1, (w * (2 if ups else 1) + 2 - 3) // stride + 1
+    emb = rnd((b, cout), dev, 34) if (stride == 1 and not ups) else None
+    res = rnd((b, ho, wo, cout), dev, 35).to(dt) if (stride == 1 and not ups) else None
+    kw = dict(stride=stride, upsample=ups, emb=emb, res=res)
+    monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: 1)
+    monkeypatch.setattr(ops, "FORCE_TILE_M", 128)
+    large = ops.conv3x3(xi, pw, **kw)
+    monkeypatch.setattr(ops, "FORCE_TILE_N", 64)
+    small = ops.conv3x3(xi, pw, **kw)
+    assert torch.equal(small, large)
+    xin = F.interpolate(qd(x), scale_factor=2, mode="nearest") if ups else qd(x)
+    ref = F.conv2d(xin, qd(wt), bias, stride=stride, padding=1)
+    if emb is not None:
+        ref = ref + emb[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    assert rel_err(small.permute(0, 3, 1, 2), ref) < (6e-3 if dt == BF16 else 1.5e-3)
+    if pw.k >= 256:
+        monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: 3)
+        sp = ops.conv3x3(xi, pw, **kw)
+        assert rel_err(sp.permute(0, 3, 1, 2), ref) < (6e-3 if dt == BF16 else 1.5e-3)
+    monkeypatch.setattr(ops, "FORCE_TILE_N", 0)
+    monkeypatch.setattr(ops, "FORCE_TILE_M", 0)
+    monkeypatch.setattr(ops, "_auto_split_k", ops._AUTO_SPLIT_K)
+    assert ops._plan_gemm(128, 1280, 11520, 160, False, False, True, True)[3] == 64        # 8 x 8 x 1280 at UNet batch 2
+    assert ops._plan_gemm(16384, 640, 5760, 160, False, False, True, True)[3] != 64
+
+
 def test_small_tile_in_the_token_stream(dev, monkeypatch):
     """The 64-column tile as a producer and as a consumer of row statistics: a 1280-wide stream written on it carries
     40 slots per row (one per 32 columns), which the LayerNorm-folded projection reads in three batches."""
