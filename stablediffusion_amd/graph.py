@@ -1,7 +1,7 @@
 """HIP-graph replay of the UNet step.
 
-One UNet forward is ~700 kernel launches; at small batch (BASELINE config 1: batch 1, UNet batch 2 with CFG) the
-kernels are a few microseconds each and the host launch rate, not the GPU, sets the step time.  The launch sequence
+One UNet forward is ~290 kernel launches; at small batch (BASELINE config 1: batch 1, UNet batch 2 with CFG) the
+kernels are 5-40 microseconds each and an eager step sits close to the host's launch rate.  The launch sequence
 is static for fixed shapes, so it is captured once into a hipGraph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm;
 the C-ABI calls launch on torch's current stream and are captured like any other launch) and replayed per step:
 the only per-step host work is two small copies into the static input buffers and one graph launch.
