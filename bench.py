@@ -228,7 +228,7 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype, peaks, step_ms
     # HBM-side bytes per launch of each family: PMC figures of separate rocprofv3 passes over this same command,
     # committed under profiles/ (counters cannot be read from inside the process); null when the file is absent
     traffic, tnote = None, "no profiles/r0?_traffic.json"
-    for name in ("r03d_traffic.json", "r03c_traffic.json", "r03b_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for name in ("r03e_traffic.json", "r03d_traffic.json", "r03c_traffic.json", "r03b_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as fh:
