@@ -1255,6 +1255,29 @@ def test_ddim_step(dev, v_param, cfg):
     assert rel_err(p0, pred) < 1e-5
 
 
+@pytest.mark.parametrize("v_param", [False, True])
+def test_ddim_step_full_size_repeated(dev, v_param):
+    """The update on a batch-16 768^2 latent (thousands of workgroups, several per CU), thirty launches in a row, every
+    element of every launch against the formula: the kernel holds the library's one packed multiply whose second source is
+    half-swapped (v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]) - a cousin of the packed-fma form that lost products under
+    co-resident workgroups; this form has not."""
+    ops = _ops()
+    x, mo, noise = rnd((16, 4, 96, 96), dev, 1), rnd((32, 4, 96, 96), dev, 2), rnd((16, 4, 96, 96), dev, 3)
+    a_t, a_prev, sig = 0.37, 0.52, 0.05
+    s1m = math.sqrt(1 - a_t)
+    o = mo[:16] + 7.5 * (mo[16:] - mo[:16])
+    if v_param:
+        e_t, pred = math.sqrt(a_t) * o + s1m * x, math.sqrt(a_t) * x - s1m * o
+    else:
+        e_t, pred = o, (x - s1m * o) / math.sqrt(a_t)
+    ref = math.sqrt(a_prev) * pred + math.sqrt(1 - a_prev - sig ** 2) * e_t + sig * noise
+    tol = 2e-5 * ref.abs().max().item()
+    for _ in range(30):
+        xp, p0 = ops.ddim_step(x, mo, a_t, a_prev, sig, s1m, guidance_scale=7.5, cfg=True, v_param=v_param, noise=noise,
+                               want_pred_x0=True)
+        assert (xp - ref).abs().max().item() < tol and (p0 - pred).abs().max().item() < 2e-5 * pred.abs().max().item()
+
+
 def test_image_to_u8_and_cast(dev):
     ops = _ops()
     x = rnd((2, 3, 16, 16), dev, 1)
