@@ -223,8 +223,11 @@ __device__ __forceinline__ void lnf_apply(const sdmi_gemm_args& p, f32x4 (&acc)[
         // source of two of the packed fmas - v_pk_fma_f32 d, cs, mean, d op_sel:[0,1,0] - and on this part that form dropped
         // the product from the LOW result in lanes 48-63 now and then, whenever two of these workgroups shared a CU (the
         // 128 x 64 tile past 256 blocks: a handful of outputs per launch came out as if the mean were zero; 28 of 30
-        // launches; never with the mean broadcast from the first source, which is what this form compiles to.
-        // tests/test_host_cpu.py::test_no_packed_fma_with_a_broadcast_second_source keeps the form out of the library.)
+        // launches; never with the mean broadcast from the first source, which is what this form compiles to.  The instruction
+        // alone computes correctly under the same co-residency (tools/micro/pk_fma_opsel_probe.hip), so the cause is an
+        // interaction of that compiled sequence and is open; tests/test_host_cpu.py::
+        // test_no_packed_fma_with_a_broadcast_second_source keeps the form out of the library and
+        // test_small_tile_in_the_token_stream repeats the launches that showed it.)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

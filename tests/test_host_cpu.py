@@ -467,10 +467,11 @@ def test_layernorm_fold_algebra_of_the_packers():
 
 def test_no_packed_fma_with_a_broadcast_second_source():
     """A guard on the built library's machine code (needs llvm-objdump, no GPU).  v_pk_fma_f32 with the broadcast operand on
-    its SECOND source (op_sel:[0,1,0]) lost the low product in lanes 48-63 now and then on MI355X when two 8-wave workgroups
-    shared a CU (found with the 128 x 64 tile's LayerNorm-folded epilogue, round 3: csrc/sdmi_gemm_kernel.h lnf_apply); the
-    source forms in use compile to the first-source broadcast, and this test fails if a compiler change brings the other
-    form back anywhere in libsdmi_hip.so."""
+    its SECOND source (op_sel:[0,1,0]) came out without its low product in lanes 48-63 now and then on MI355X when two 8-wave
+    workgroups shared a CU (the 128 x 64 tile's LayerNorm-folded epilogue, round 3: csrc/sdmi_gemm_kernel.h lnf_apply).  The
+    instruction alone is fine (tools/micro/pk_fma_opsel_probe.hip), the cause inside that compiled sequence is open; the
+    source forms in use compile to the first-source broadcast, which never showed it, and this test fails if a compiler
+    change brings the other form back anywhere in libsdmi_hip.so."""
     import struct
     from stablediffusion_amd import hip
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
