@@ -571,6 +571,17 @@ def test_batched_gemm(dev):
     out = ops.gemm_nt_batched(a1.to(BF16), b.to(BF16), BF16, bias_rows=bias)
     ref = torch.einsum("mk,znk->zmn", q(a1[0]), q(b)) + bias[None, :, None]
     assert rel_err(out, ref) < 6e-3
+    # the same batched problem on the 64-column tile through the C ABI (per-row bias: the general epilogue path)
+    ab, bb = a1.to(BF16).contiguous(), b.to(BF16).contiguous()
+    o64 = torch.empty(z, m, n, dtype=BF16, device=dev)
+    g = ops.hip.GemmArgs()
+    g.mode, g.A, g.lda, g.M, g.W, g.N, g.K = 0, ab.data_ptr(), k, m, bb.data_ptr(), n, k
+    g.out, g.ld_out, g.out_kind, g.dtype, g.alpha, g.batch, g.split_k = o64.data_ptr(), n, 0, 0, 1.0, z, 1
+    g.stride_a, g.stride_w, g.stride_out = 0, n * k, m * n
+    g.bias, g.bias_per_row, g.tile_n, g.tile_m = bias.data_ptr(), 1, 64, 64
+    assert ops.hip.lib().sdmi_gemm(C.byref(g), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o64, out)
 
 
 # ----------------------------------------------------------------------------- norms
