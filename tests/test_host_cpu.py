@@ -500,3 +500,26 @@ def test_no_packed_fma_with_a_broadcast_second_source():
                     hits.append((name, line.strip()))
     assert kernels > 50, kernels
     assert not hits, hits[:4]
+
+
+def test_plan_takes_the_small_tile_where_it_was_measured_to_win():
+    """ops._plan_gemm (pure host logic): the 64-column tile for the launches of a few hundred rows - the UNet's
+    projections at batch 2, the 8 x 8 level, the one-row-tile convs - and the larger tiles everywhere the sweeps
+    (profiles/r03d_small_tile_sweep.txt, r03d_small_conv_sweep.txt) showed them ahead."""
+    from stablediffusion_amd import ops
+    lin = lambda m, n, k, small=True: ops._plan_gemm(m, n, k, 160, False, False, small, False)
+    conv = lambda m, n, cin, small=True: ops._plan_gemm(m, n, 9 * cin, 160, False, False, small, True)
+    assert lin(512, 1280, 1280) == (64, 1, 3, 64) and lin(128, 1280, 1280) == (64, 1, 3, 64)
+    assert lin(2048, 640, 640) == (128, 1, 3, 64) and lin(8192, 320, 320) == (128, 1, 3, 64)
+    assert lin(2048, 640, 2560) == (128, 1, 3, 64)              # replaces split 4 + reduce
+    assert lin(512, 1280, 5120)[3] == 160 and lin(512, 1280, 5120)[1] > 1      # long K against the rows: stays split
+    for big in ((65536, 320, 320), (16384, 640, 640), (4096, 1280, 1280), (65536, 960, 320), (8192, 960, 320)):
+        assert lin(*big)[3] == 160, big
+    assert lin(512, 1280, 1280, small=False)[3] == 160
+    assert conv(128, 1280, 1280)[3] == 64 and conv(128, 1280, 1280)[1] > 1    # one row tile: split on the small tile
+    assert conv(8192, 320, 320) == (128, 1, 3, 64) and conv(4096, 320, 320) == (128, 1, 3, 64)
+    for big in ((512, 1280, 2560), (2048, 640, 640), (8192, 320, 640), (16384, 640, 640), (65536, 320, 320), (1024, 1280, 1280)):
+        assert conv(*big)[3] == 160, big
+    # GEGLU and weights without whole 64-row tiles never take it (the caller's small_ok), and a split is only planned
+    # on the small tile for convs of at most 256 rows
+    assert all(conv(m, 1280, 1280)[1] == 1 or conv(m, 1280, 1280)[3] == 160 for m in (512, 1024, 2048))
