@@ -189,7 +189,52 @@ def family_table(populations, peaks=None):
             pm = peaks["mfma_tflops"] if mfma else peaks["hbm_tbs"]
             fam[kind]["peak_measured"] = pm
             fam[kind]["frac_measured"] = ach / pm if pm else None
+    # the same launches on the roofline *model* (per launch the larger of its MFMA and its HBM time, nominal peaks)
+    for kind, e in roofline_model(populations, MFMA_PEAK_TFLOPS * 1e12, HBM_PEAK_TBS * 1e12).items():
+        fam[kind]["roofline_model"] = e
     return fam, t_all
+
+
+def launch_bytes(kind, work, shp):
+    """Compulsory HBM bytes of one traced launch: every operand read once, the result written once (16-bit operands;
+    what the launch would move if nothing were re-read).  With the FLOPs this places the launch on the roofline:
+    attainable time = max(FLOPs / MFMA peak, bytes / HBM peak)."""
+    if kind in ("groupnorm", "layernorm"):
+        return work                                        # (their `work` already is one read + one write)
+    if kind == "attention":
+        nb, heads, nq, nk = shp[:4]
+        return nb * heads * (2 * nq + 2 * nk) * 64 * 2     # q, o and k, v
+    m, n_w, k, stride, upsample, geglu, res, out32, batch = (tuple(shp) + (0, 0, 0, 0, 1))[:9] if len(shp) < 9 else shp
+    n_out = n_w // 2 if geglu else n_w
+    if kind == "conv3x3":
+        pixels_in = m * stride * stride // (4 if upsample else 1)
+        a_bytes = pixels_in * (k // 9) * 2
+    else:
+        a_bytes = m * k * 2
+    return batch * (a_bytes + n_w * k * 2 + m * n_out * (4 if out32 else 2) + (m * n_out * 2 if res else 0))
+
+
+def roofline_model(populations, peak_flops, peak_bytes):
+    """Per family: sum over launches of max(FLOPs / peak_flops, bytes / peak_bytes) against the measured durations, and
+    the share of the family's time spent in launches whose byte term is the larger one (HBM-bound by the model)."""
+    out = {}
+    for kind in FAMILY_NAMES:
+        t_roof = t_meas = t_hbm = 0.0
+        for rep, tr in populations:
+            for k, f, t, _, shp in tr:
+                if k != kind:
+                    continue
+                fl = f if kind in ("conv3x3", "linear", "attention") else 0.0
+                tb = launch_bytes(kind, f, shp) / peak_bytes
+                tf = fl / peak_flops
+                t_roof += rep * max(tf, tb)
+                t_meas += rep * t
+                if tb > tf:
+                    t_hbm += rep * t
+        if t_meas:
+            out[kind] = {"frac": t_roof / t_meas, "attainable_ms": t_roof * 1e3, "measured_ms": t_meas * 1e3,
+                         "hbm_bound_time_share": t_hbm / t_meas}
+    return out
 
 
 def executed_flops(tr):
@@ -248,7 +293,10 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype, peaks, step_ms
                         "(split-K reduce launches and the event-to-event gap included, so the brackets of a step add up "
                         "to MORE than the step takes - bracket_sum_ms_per_step vs step_ms: fractions are conservative, "
                         "time_share is relative to the bracket sum); frac = against the nominal 2.5 PFLOP/s dense 16-bit "
-                        "peak / the 8 TB/s HBM spec, frac_measured = against peaks_measured (this box, this run)"})
+                        "peak / the 8 TB/s HBM spec, frac_measured = against peaks_measured (this box, this run); "
+                        "roofline_model.frac = sum over the family's launches of max(FLOPs / 2.5 PFLOP/s, compulsory bytes / "
+                        "8 TB/s) over their measured time - a launch of low intensity (K = 320 projections: 107 FLOP/B "
+                        "against a machine balance of 312) is priced at its HBM time there, not at the MFMA peak"})
     return top, executed_flops(un), executed_flops(de)
 
 

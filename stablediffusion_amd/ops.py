@@ -434,7 +434,8 @@ def _run_gemm(a, what):
     hip.check(hip.lib().sdmi_gemm(C.byref(a), _stream()), what)
     e1.record()
     TRACE.append(("conv3x3" if a.mode == 1 else "linear", _gemm_flops(a), e0, e1, int(a.split_k),
-                  (int(a.M), int(a.N) * (2 if a.geglu else 1), int(a.K), int(a.stride), int(a.upsample))))
+                  (int(a.M), int(a.N) * (2 if a.geglu else 1), int(a.K), int(a.stride), int(a.upsample),
+                   int(a.geglu), 1 if a.res else 0, int(a.out_kind != 0), max(int(a.batch), 1))))
 
 
 _NARROW_MAX_CIN = 512     # csrc/sdmi_conv_narrow.hip NARROW_MAX_CIN
@@ -682,7 +683,7 @@ def xattn_block(x, ln, pw_q, pw_o, k, v, nk, heads, scale, rows_per_image, row_s
         a.row_stats_out, a.row_stats_slots = st_o.data_ptr(), 4
     # (one MFMA family for bench.py's table: the launch is counted with the linears - 2 of its 3 contractions are)
     flops = 2 * m * 320 * 320 * 2 + 4 * m * nk * 320
-    _traced("linear", flops, (m, 320, 320, 0, 0), lambda: hip.check(hip.lib().sdmi_xattn_block(C.byref(a), _stream()), "sdmi_xattn_block"))
+    _traced("linear", flops, (m, 320, 320, 0, 0, 0, 0, 0, 1), lambda: hip.check(hip.lib().sdmi_xattn_block(C.byref(a), _stream()), "sdmi_xattn_block"))
     return (out, (st_o, 4) if row_stats else None) if row_stats else out
 
 
