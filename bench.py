@@ -204,7 +204,7 @@ def launch_bytes(kind, work, shp):
     if kind == "attention":
         nb, heads, nq, nk = shp[:4]
         return nb * heads * (2 * nq + 2 * nk) * 64 * 2     # q, o and k, v
-    m, n_w, k, stride, upsample, geglu, res, out32, batch = (tuple(shp) + (0, 0, 0, 0, 1))[:9] if len(shp) < 9 else shp
+    m, n_w, k, stride, upsample, geglu, res, out32, batch = tuple(shp) + (0, 0, 0, 1)[max(len(shp) - 5, 0):]
     n_out = n_w // 2 if geglu else n_w
     if kind == "conv3x3":
         pixels_in = m * stride * stride // (4 if upsample else 1)

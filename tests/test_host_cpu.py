@@ -523,3 +523,34 @@ def test_plan_takes_the_small_tile_where_it_was_measured_to_win():
     # GEGLU and weights without whole 64-row tiles never take it (the caller's small_ok), and a split is only planned
     # on the small tile for convs of at most 256 rows
     assert all(conv(m, 1280, 1280)[1] == 1 or conv(m, 1280, 1280)[3] == 160 for m in (512, 1024, 2048))
+
+
+def test_bench_roofline_model_prices_each_launch_at_its_larger_bound():
+    """bench.py's `roofline_model` (host logic): compulsory bytes per traced launch and, per family, the sum of
+    max(FLOPs / peak, bytes / peak) over the measured time."""
+    import bench
+    # K = 320 projection with a residual: 2 M (K + 2 N) + 2 N K bytes; 107 FLOP/B, under the machine balance of 312
+    m, n, k = 65536, 320, 320
+    shp = (m, n, k, 0, 0, 0, 1, 0, 1)
+    by = bench.launch_bytes("linear", 2 * m * n * k, shp)
+    assert by == 2 * (m * k + n * k + 2 * m * n)
+    assert 100 < 2 * m * n * k / by < 110
+    # GEGLU halves the stored columns; an fp32 output doubles its bytes; batched launches multiply
+    assert bench.launch_bytes("linear", 0, (128, 640, 64, 0, 0, 1, 0, 0, 1)) == 2 * (128 * 64 + 640 * 64 + 128 * 320)
+    assert bench.launch_bytes("linear", 0, (128, 640, 64, 0, 0, 0, 0, 1, 3)) == 3 * (2 * (128 * 64 + 640 * 64) + 4 * 128 * 640)
+    # conv3x3: the input image once (stride 2 reads four times the output pixels, the x2 upsample a quarter)
+    assert bench.launch_bytes("conv3x3", 0, (1024, 64, 9 * 32, 1, 0, 0, 0, 0, 1)) == 2 * (1024 * 32 + 64 * 288 + 1024 * 64)
+    assert bench.launch_bytes("conv3x3", 0, (1024, 64, 9 * 32, 2, 0, 0, 0, 0, 1)) == 2 * (4096 * 32 + 64 * 288 + 1024 * 64)
+    assert bench.launch_bytes("conv3x3", 0, (1024, 64, 9 * 32, 1, 1, 0, 0, 0, 1)) == 2 * (256 * 32 + 64 * 288 + 1024 * 64)
+    assert bench.launch_bytes("attention", 0, (2, 5, 4096, 77)) == 2 * 5 * (2 * 4096 + 2 * 77) * 64 * 2
+    assert bench.launch_bytes("groupnorm", 12345, (2, 64, 320)) == 12345
+    # a 5-field shape (older traces) still prices: no residual, 16-bit output, one batch
+    assert bench.launch_bytes("linear", 0, (128, 640, 64, 0, 0)) == 2 * (128 * 64 + 640 * 64 + 128 * 640)
+    tr = [("linear", 2 * m * n * k, 40e-6, 1, shp),                                    # HBM-bound by the model
+          ("linear", 2 * 4096 * 1280 * 1280, 20e-6, 1, (4096, 1280, 1280, 0, 0, 0, 0, 0, 1))]      # MFMA-bound
+    rm = bench.roofline_model([(2, tr)], 2.5e15, 8e12)["linear"]
+    t0, t1 = by / 8e12, 2 * 4096 * 1280 * 1280 / 2.5e15
+    assert abs(rm["frac"] - (t0 + t1) / 60e-6) < 1e-9
+    assert abs(rm["hbm_bound_time_share"] - 40 / 60) < 1e-9
+    fam, _ = bench.family_table([(1, tr)])
+    assert fam["linear"]["roofline_model"]["frac"] > fam["linear"]["frac"]
