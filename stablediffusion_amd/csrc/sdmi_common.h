@@ -168,6 +168,9 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // below the fp16 / bf16 rounding of the output).  20 VALU issues per PAIR (two v_med3, 16 v_pk_fma / v_pk_mul + the
 // gate product) against ~25 per value for the form above, whose rcp and exp run at quarter rate.
 __device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 g) {
+#ifdef SDMI_DEBUG_NO_GELU      // timing experiment only (results wrong): what the GELU's VALU work costs a GEGLU launch
+    return g * 0.5f;
+#else
     constexpr float GC = 4.9497476f;
     f32x2 gc;
     gc[0] = __builtin_amdgcn_fmed3f(g[0], -GC, GC);
@@ -180,6 +183,7 @@ __device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 g) {
     for (int i = 11; i >= 0; --i) q = __builtin_elementwise_fma(q, z, (f32x2){c[i], c[i]});
     const f32x2 hg = g * 0.5f;
     return __builtin_elementwise_fma(hg * gc, q, hg);
+#endif
 }
 __device__ __forceinline__ f32x4 gelu_erf_f4(const f32x4& g) {
     const f32x2 lo = gelu_erf_pk((f32x2){g[0], g[1]}), hi = gelu_erf_pk((f32x2){g[2], g[3]});
