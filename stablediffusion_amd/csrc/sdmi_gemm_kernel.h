@@ -12,6 +12,9 @@
 #endif
 
 #ifndef SDMI_DEBUG_A_FILL_NINTH
+#ifndef SDMI_DEBUG_HALF_FRAG_READS
+#define SDMI_DEBUG_HALF_FRAG_READS 0   // timing experiment only (results wrong): every second fragment read of the k-loop is dropped (the compiler merges the duplicate addresses) - what the LDS reads cost the k-step
+#endif
 #define SDMI_DEBUG_A_FILL_NINTH 0   // timing experiment only (results wrong, ring waits under-counted): the conv's A tile is moved into LDS on every ninth k-tile only - the LDS fill bytes of a halo-tile kernel (each input pixel staged once per channel chunk instead of once per tap) with everything else unchanged
 #endif
 
@@ -707,8 +710,10 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
     do {                                                                                                   \
         const uint4* St_ = lds + (STAGE) * STAGE_CHUNKS;                                                   \
         const int pc_ = ((KS) * 4 + fq) ^ (frow & 7);                                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) AF[i_] = St_[a_base + i_ * 128 + pc_];           \
-        _Pragma("unroll") for (int i_ = 0; i_ < TN; ++i_) WF[i_] = St_[w_base + i_ * 128 + pc_];           \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                                  \
+            AF[i_] = St_[a_base + (SDMI_DEBUG_HALF_FRAG_READS ? i_ / 2 * 2 : i_) * 128 + pc_];             \
+        _Pragma("unroll") for (int i_ = 0; i_ < TN; ++i_)                                                  \
+            WF[i_] = St_[w_base + (SDMI_DEBUG_HALF_FRAG_READS ? i_ / 2 * 2 : i_) * 128 + pc_];             \
     } while (0)
 #define SDMI_MFMA_HALF(AF, WF)                                                                             \
     do {                                                                                                   \
