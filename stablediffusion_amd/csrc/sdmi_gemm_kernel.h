@@ -15,10 +15,20 @@
 #ifndef SDMI_DEBUG_HALF_FRAG_READS
 #define SDMI_DEBUG_HALF_FRAG_READS 0   // timing experiment only (results wrong): every second fragment read of the k-loop is dropped (the compiler merges the duplicate addresses) - what the LDS reads cost the k-step
 #endif
+#ifndef SDMI_DEBUG_ABLATE
+#define SDMI_DEBUG_ABLATE 0   // timing experiments only (results wrong), the k-loop of the tiled kernel with one component removed: 1 = no MFMA (the fragments are still read and waited for), 2 = no LDS-DMA and no DMA wait (the stages of the prologue are re-read), 3 = no barrier, 4 = the DMA is issued but never waited for
+#endif
 #define SDMI_DEBUG_A_FILL_NINTH 0   // timing experiment only (results wrong, ring waits under-counted): the conv's A tile is moved into LDS on every ninth k-tile only - the LDS fill bytes of a halo-tile kernel (each input pixel staged once per channel chunk instead of once per tap) with everything else unchanged
 #endif
 
 namespace {
+
+#ifndef SDMI_DEBUG_CLOCKS
+#define SDMI_DEBUG_CLOCKS 0   // measurement build only: block 0 of every tiled-kernel launch leaves (shader clocks, 100 MHz ticks) of its k-loop in sdmi_debug_clk - the clock the part holds under this kernel (tools/kloop_clock.py)
+#endif
+#if SDMI_DEBUG_CLOCKS
+__device__ long long sdmi_debug_clk[2];
+#endif
 
 // Zeros: the DMA source of out-of-image conv taps and padded rows / columns (the DMA cannot mask).  Long enough
 // that a tap's pointer can walk a whole channel run (Cin <= ZERO_ELEMS) without leaving it.
@@ -718,9 +728,16 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
 #define SDMI_MFMA_HALF(AF, WF)                                                                             \
     do {                                                                                                   \
         if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                   \
+        if (SDMI_DEBUG_ABLATE == 1) {                                                                      \
+            _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
+                asm volatile("" :: "v"(AF[mi_].x), "v"(AF[mi_].y), "v"(AF[mi_].z), "v"(AF[mi_].w));        \
+            _Pragma("unroll") for (int ni_ = 0; ni_ < TN; ++ni_)                                           \
+                asm volatile("" :: "v"(WF[ni_].x), "v"(WF[ni_].y), "v"(WF[ni_].z), "v"(WF[ni_].w));        \
+        } else {                                                                                           \
         _Pragma("unroll") for (int ni_ = 0; ni_ < TN; ++ni_)                                               \
             _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
                 acc[ni_][mi_] = mfma16<DT>(WF[ni_], AF[mi_], acc[ni_][mi_]);                               \
+        }                                                                                                  \
         if (SDMI_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                   \
     } while (0)
 
@@ -738,6 +755,10 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
 #define SDMI_INTERLEAVE() do {} while (0)
 #endif
 
+#if SDMI_DEBUG_CLOCKS
+    long long dbg_c0 = 0, dbg_w0 = 0;
+    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
+#endif
     int kt_issue = 0;
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
@@ -754,13 +775,14 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         SDMI_MFMA_HALF(af0, wf0);
         int rd = 1, wr = 0;                          // ring stage of tile kt+1 / of tile kt (free after the barrier)
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            SDMI_WAIT_DMA(kt_issue - kt - 2);        // tile kt+1 landed; younger tiles may still fly
-            __syncthreads();                         // every wave has finished READING tile kt as well
+            if (SDMI_DEBUG_ABLATE != 2 && SDMI_DEBUG_ABLATE != 4) SDMI_WAIT_DMA(kt_issue - kt - 2);        // tile kt+1 landed; younger tiles may still fly
+            if (SDMI_DEBUG_ABLATE != 3) __syncthreads();                         // every wave has finished READING tile kt as well
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SDMI_READ_FRAGS(af0, wf0, rd, 0);
             SDMI_MFMA_HALF(af1, wf1);                // second half of tile kt
             SDMI_INTERLEAVE();
-            if (kt_issue < nk) {
-                SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
+            if (kt_issue < nk) {                     // (issued right behind the barrier instead: + 3-8 % on the conv shapes, profiles/r03f_kloop_ablation.txt)
+                if (SDMI_DEBUG_ABLATE != 2) SDMI_STAGE_TILE(kt_begin + kt_issue, wr);
                 ++kt_issue;
             }
             SDMI_READ_FRAGS(af1, wf1, rd, 1);
@@ -771,6 +793,12 @@ __global__ __launch_bounds__(512, NST == 2 ? 4 : 2) void sdmi_gemm_kernel(const 
         }
         SDMI_MFMA_HALF(af1, wf1);                    // second half of the last tile
     }
+#if SDMI_DEBUG_CLOCKS
+    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
+        sdmi_debug_clk[0] = clock64() - dbg_c0;
+        sdmi_debug_clk[1] = wall_clock64() - dbg_w0;
+    }
+#endif
 
     // ---- epilogue ----
     // accumulator quad acc[ni][mi][j]: output row m = m0 + wm*16*MI + mi*16 + (lane&15),
