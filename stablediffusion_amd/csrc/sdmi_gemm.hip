@@ -18,6 +18,7 @@
 // This file: the split-K reduce kernel and the C entry point; the kernel template is instantiated per
 // (mode, dtype) in sdmi_gemm_m?_*.hip so that the units compile in parallel.
 #include <mutex>
+#include <cstdlib>
 #include "sdmi_gemm_kernel.h"
 
 namespace {
@@ -167,6 +168,7 @@ int sdmi_gemm_wide_attrs_f16();
 void sdmi_gemm_wide_launch_bf16(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 void sdmi_gemm_wide_launch_f16(int mode, dim3 grid, hipStream_t s, const sdmi_gemm_args& p);
 int sdmi_gemm_panel_launch(const sdmi_gemm_args& p, hipStream_t s);      // sdmi_gemm_panel.hip
+int sdmi_conv_halo_launch(const sdmi_gemm_args& p, hipStream_t s);       // sdmi_conv_halo.hip
 int sdmi_conv_narrow_launch(const sdmi_gemm_args& p, hipStream_t s);     // sdmi_conv_narrow.hip
 
 // Row tile the launcher picks: 256 rows once that still gives every CU a block, else 128 rows.
@@ -367,7 +369,18 @@ extern "C" int sdmi_gemm(const sdmi_gemm_args* a, void* stream) {
     const bool f16 = p.dtype == SDMI_DTYPE_F16;
     const int wide = BN == 160, tall = BM == 256;
     const int variant = tall ? 1 : (p.stages == 2 ? 2 : 0);
-    if (BN == 64 && p.mode == 1) {
+    // conv3x3 on whole row strips of a 16 | 32 | 64-pixel-wide image: the halo-tile kernel (sdmi_conv_halo.hip) where it applies
+    // (SDMI_CONV_HALO=0: development switch back to the tiled kernel)
+    static const bool halo_on = [] { const char* e = getenv("SDMI_CONV_HALO"); return e == nullptr || e[0] != '0'; }();
+    int halo_status = 0;
+    if (halo_on && p.mode == 1 && BN == 160 && BM == 256 && p.algo == 0) {
+        sdmi_gemm_args ph = p;
+        ph.tile_n = BN; ph.tile_m = BM;
+        halo_status = sdmi_conv_halo_launch(ph, s);
+        if (halo_status < 0) return halo_status;
+    }
+    if (halo_status == 1) {
+    } else if (BN == 64 && p.mode == 1) {
         (f16 ? sdmi_gemm_small_conv_launch_m1_f16 : sdmi_gemm_small_conv_launch_m1_bf16)(grid, s, p);
     } else if (BN == 64) {
         if (p.ln_colsum != nullptr || p.row_stats_out != nullptr) sdmi_gemm_small_launch_m0_f16_lnf(BM == 64, grid, s, p);

@@ -319,6 +319,44 @@ def test_small_tile_conv3x3(dev, dt, b, h, w, cin, cout, stride, ups, monkeypatc
     assert ops._plan_gemm(16384, 640, 5760, 160, False, False, True, True)[3] != 64
 
 
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("b,h,w,cin,cout,split", [(1, 16, 16, 128, 320, 1), (3, 16, 16, 192, 160, 1), (2, 32, 32, 64, 640, 1),
+                                                 (1, 64, 64, 128, 320, 1), (2, 32, 16, 256, 480, 1), (1, 16, 16, 256, 320, 2),
+                                                 (2, 32, 32, 320, 160, 3)])
+def test_conv3x3_halo_tiles(dev, dt, b, h, w, cin, cout, split, monkeypatch):
+    """The halo-tile conv3x3 kernel (sdmi_conv_halo.hip: whole row strips of a 16 | 32 | 64-pixel-wide image on the 256 x 160 tile, the
+    activation tile staged once per 64-channel chunk) against the tiled kernel (FORCE_ALGO = 1) and torch's conv2d: bias +
+    embedding rows + residual, several images per launch, strips in the middle of an image (64 x 64: 16 blocks), one chunk
+    and several, split-K over chunks.  K runs chunk-major there, so the two kernels agree to fp32 rounding of the sums,
+    not bit for bit; the second launch of each must reproduce the first."""
+    ops = _ops()
+    qd = lambda t: t.to(dt).float()
+    x = rnd((b, cin, h, w), dev, 41)
+    wt, bias = rnd((cout, cin, 3, 3), dev, 42, (9 * cin) ** -0.5), rnd((cout,), dev, 43)
+    xi = x.permute(0, 2, 3, 1).contiguous().to(dt)
+    pw = ops.pack_conv3x3(wt, bias, dtype=dt)
+    emb = rnd((b, cout), dev, 44)
+    res = rnd((b, h, w, cout), dev, 45).to(dt)
+    monkeypatch.setattr(ops, "_auto_split_k", lambda m_, n_, k_, t_=128: split)
+    monkeypatch.setattr(ops, "FORCE_TILE_M", 256)
+    halo = ops.conv3x3(xi, pw, emb=emb, res=res)
+    halo2 = ops.conv3x3(xi, pw, emb=emb, res=res)
+    assert torch.equal(halo, halo2)
+    monkeypatch.setattr(ops, "FORCE_ALGO", 1)
+    tiled = ops.conv3x3(xi, pw, emb=emb, res=res)
+    monkeypatch.setattr(ops, "FORCE_ALGO", 0)
+    ref = F.conv2d(qd(x), qd(wt), bias, padding=1) + emb[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    tol = 6e-3 if dt == BF16 else 1.5e-3
+    assert rel_err(halo.permute(0, 3, 1, 2), ref) < tol
+    assert rel_err(tiled.permute(0, 3, 1, 2), ref) < tol
+    # the two kernels against each other: the same products summed in another order, then rounded to 16 bits
+    assert rel_err(halo.float(), tiled.float()) < (4e-3 if dt == BF16 else 5e-4)
+    assert not torch.equal(halo, tiled) or cin == 64      # (one chunk: the same order - else this test is not reaching the new kernel)
+    # no residual / embedding, 16-bit output straight from the accumulators
+    plain = ops.conv3x3(xi, pw)
+    assert rel_err(plain.permute(0, 3, 1, 2), F.conv2d(qd(x), qd(wt), bias, padding=1)) < tol
+
+
 def test_small_tile_in_the_token_stream(dev, monkeypatch):
     """The 64-column tile as a producer and as a consumer of row statistics: a 1280-wide stream written on it carries
     40 slots per row (one per 32 columns), which the LayerNorm-folded projection reads in three batches."""
