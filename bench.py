@@ -112,7 +112,7 @@ def cpu_baseline(model, h, ddim_steps, scale):
             "unet_step_s": t_step, "decode_s": t_dec}
 
 
-FAMILY_NAMES = {"conv3x3": "sdmi_gemm_kernel<1,...> (implicit-GEMM conv3x3, MFMA 16x16x32)",
+FAMILY_NAMES = {"conv3x3": "sdmi_conv_halo_kernel + sdmi_gemm_kernel<1,...> (implicit-GEMM conv3x3, MFMA 16x16x32)",
                 "linear": "sdmi_gemm_kernel<0,...> (linear / conv1x1, MFMA 16x16x32)",
                 "attention": "attn_fwd_d64_kernel (flash attention d=64, MFMA 32x32x16)",
                 "groupnorm": "gn_stats_kernel + gn_apply_kernel (GroupNorm(32)+SiLU)", "layernorm": "layernorm_kernel"}
@@ -273,7 +273,7 @@ def roofline(model, sampler, B, h, ddim_steps, c, uc, x_T, dtype, peaks, step_ms
     # HBM-side bytes per launch of each family: PMC figures of separate rocprofv3 passes over this same command,
     # committed under profiles/ (counters cannot be read from inside the process); null when the file is absent
     traffic, tnote = None, "no profiles/r0?_traffic.json"
-    for name in ("r03e_traffic.json", "r03d_traffic.json", "r03c_traffic.json", "r03b_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for name in ("r03g_traffic.json", "r03e_traffic.json", "r03d_traffic.json", "r03c_traffic.json", "r03b_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as fh:

@@ -115,7 +115,10 @@ typedef struct sdmi_gemm_args {
     int32_t res_f32;                    /* 1: `res` is fp32 (only with an fp32 out_kind) - the fp32 mode of the path */
     int32_t stages;                     /* LDS ring depth: 0 | 3 = three stages; 2 (128-row tile only) = two stages,
                                            two blocks per CU - for short K */
-    int32_t algo;                       /* 0 = the library picks (incl. the narrow conv3x3 kernel for N <= 16, stride 1); 1 = the tiled kernel; 2 = the A-panel-stationary kernel
+    int32_t algo;                       /* 0 = the library picks (incl. the narrow conv3x3 kernel for N <= 16, stride 1, and - for stride-1 conv3x3 over whole
+                                           256-pixel row strips of a 16 | 32 | 64-pixel-wide image on the 256 x 160 tile - the halo-tile kernel of
+                                           sdmi_conv_halo.hip, which sums K channel-chunk-major: its results equal the tiled kernel's to fp32
+                                           rounding of the sums, not bit for bit); 1 = the tiled kernel; 2 = the A-panel-stationary kernel
                                            (mode 0, K == 320, 16-bit output, N_w % 160 == 0 or GEGLU: every workgroup keeps
                                            its rows of A in LDS and streams all of W) - SDMI_ERR_BAD_ARG if it does not apply */
     /* ln_gamma non-NULL: A is first layer-normalised over its K columns, y = (a - mean) * rstd * ln_gamma[k] + ln_beta[k]

@@ -9,7 +9,7 @@ import collections, csv, json, sys
 
 
 def kernel_class(k):
-    if "sdmi_gemm_kernel<1" in k or "conv3x3_narrow_kernel" in k or "sdmi_gemm_wide_kernel<1" in k: return "conv"
+    if "sdmi_gemm_kernel<1" in k or "conv3x3_narrow_kernel" in k or "sdmi_gemm_wide_kernel<1" in k or "sdmi_conv_halo_kernel" in k: return "conv"
     if "sdmi_gemm_kernel<0" in k or "sdmi_gemm_wide_kernel<0" in k: return "linear_tiled"
     if "sdmi_gemm_panel_kernel" in k: return "linear_panel"
     if "splitk_reduce" in k: return "splitk_reduce"
