@@ -7,9 +7,10 @@
 // (256 / W + 2) * W <= 384 pixels x 128 B = 48 KiB - and the nine taps of the chunk read it through tap-shifted
 // fragment addresses: K runs chunk-major (k-tile j = chunk * 9 + tap; the weights stay packed tap-major, tile j reads
 // columns tap * Cin + chunk * 64).  Left / right neighbours of the first / last pixel of an image row are zero: the
-// fragment registers of those lanes are cleared (the halo has no pad columns); rows above / below the image come from
-// the zero page.  LDS: two halo buffers (the next chunk lands under the nine taps of this one) + the 3-stage W ring =
-// 1 KiB of pad + 96 + 60 KiB.  Bytes into LDS per k-tile: 20 (W) + 48 / 9 = 25.3 KB against 52 KB.
+// halo has no pad columns - those lanes read a zero pixel kept in front of the buffers instead (a select on the address);
+// rows above / below the image come from the zero page.  LDS: 1 KiB of pad (the zero pixel), two halo buffers (the next
+// chunk lands under the nine taps of this one) and the 3-stage W ring = 1 + 96 + 60 KiB.  Bytes into LDS per k-tile:
+// 20 (W) + 48 / 9 = 25.3 KB against 52 KB.
 // Block tile 256 x 160 x 64, 8 waves, fragment layout / swizzle / MFMA roles / half-k-tile pipeline of sdmi_gemm_kernel.h;
 // the accumulation order over K differs from mode 1 (chunk-major), so results agree with it to fp32 rounding, not bit for bit.
 #include "sdmi_gemm_kernel.h"
